@@ -1,0 +1,137 @@
+/*
+ * glvoc -- C ABI of the MI355X (gfx950) Griffin-Lim vocoder library, libglvoc.so.
+ *
+ * The reference has no FFI for this path: its boundary is the Python function
+ *     mel_to_audio_griffin_lim(mel_db, mean, std, sr, n_fft, hop_length,
+ *                              win_length, n_mels, fmax) -> ndarray
+ * (reference vocoder/mel_audio.py:112-132, copies at vocoder/pra.py:65-80 and
+ * test.py:143-158).  Each entry point below replaces one stage of that
+ * function and cites the line it stands in for.  A binding needs nothing but
+ * plain pointers and sizes: tts_amd/_lib.py binds these with ctypes, passing
+ * torch device pointers (Tensor.data_ptr()) and the raw hipStream_t.
+ *
+ * Conventions
+ *   - Every function returns GLV_OK (0) or a negative glv_status;
+ *     glv_last_error() returns a thread-local message for the last failure.
+ *   - Pointers named *_dev are device memory owned by the caller; pointers
+ *     named *_host are host memory read before the call returns.
+ *   - All work is enqueued on `stream` (a hipStream_t, NULL = default stream)
+ *     and is asynchronous; only glv_plan_create/destroy synchronise.
+ *   - A plan is bound to one device and must be used from one stream at a time.
+ *   - Layouts are frame-major: mel (B, T, n_mels), spectra (B, T, F) with
+ *     F = n_fft/2+1 contiguous per frame, waveforms (B, y_stride).  `T` is the
+ *     common row stride in frames (frames_stride); the true frame count of
+ *     utterance b is n_frames_host[b] <= frames_stride <= max_frames.
+ *   - Complex values are interleaved (re, im) float pairs.
+ */
+#ifndef GLVOC_H
+#define GLVOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct glv_plan glv_plan;
+
+typedef enum glv_status {
+    GLV_OK = 0,
+    GLV_ERR_INVALID = -1,     /* bad argument (shape, size, null pointer)          */
+    GLV_ERR_UNSUPPORTED = -2, /* n_fft / hop combination the kernels do not cover  */
+    GLV_ERR_HIP = -3,         /* a HIP runtime call failed                         */
+    GLV_ERR_STATE = -4        /* call order (e.g. inverse basis not set)           */
+} glv_status;
+
+/* Library version: major*10000 + minor*100 + patch. */
+int glv_version(void);
+
+/*
+ * Creates the per-shape state: window / twiddle / window-sum-square tables and
+ * the device workspace of the iteration loop.  Stands in for the keyword
+ * defaults of the reference signature (vocoder/mel_audio.py:112).
+ * Supported: n_fft in {1024, 2048}; hop in {128, 256, 512} with
+ * hop <= n_fft/2; win_length <= n_fft (periodic Hann, centred zero padding).
+ */
+int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_length, int n_mels,
+                    int max_frames, int max_batch, int device);
+
+void glv_plan_destroy(glv_plan* plan);
+
+/* Bytes of device memory the plan holds. */
+int64_t glv_plan_workspace_bytes(const glv_plan* plan);
+
+/*
+ * Uploads the (F, n_mels) row-major float32 pseudo-inverse of the mel basis,
+ * i.e. the result of np.linalg.pinv(librosa.filters.mel(...)) computed on the
+ * host (reference vocoder/mel_audio.py:121-122).
+ */
+int glv_plan_set_inverse_basis(glv_plan* plan, const float* pinv_FxM_host);
+
+/*
+ * Denormalise, dB -> power, and multiply by the inverse basis
+ * (reference vocoder/mel_audio.py:114, :118, :123):
+ *     S[b, t, :] = pinv @ 10 ** (0.1 * (mel_db[b, t, :] * std + mean))
+ * mel_db_dev: (batch, frames_stride, n_mels) float32.  S_dev: (batch,
+ * frames_stride, F) float32.  All frames_stride rows are computed.
+ */
+int glv_mel_invert(glv_plan* plan, const float* mel_db_dev, int batch, int frames_stride,
+                   float mean, float std, float* S_dev, void* stream);
+
+/*
+ * librosa.griffinlim(S, n_iter, hop_length, win_length, momentum, init='random')
+ * as called at reference vocoder/mel_audio.py:126 (window='hann', center=True,
+ * pad_mode='constant').
+ *   S_dev        (batch, frames_stride, F) float32 "magnitudes" (may be negative).
+ *   phase0_dev   (batch, frames_stride, F) interleaved unit phasors, or NULL to
+ *                draw them on the device from `seed` (counter-based generator;
+ *                not numpy's stream).
+ *   y_dev        (batch, y_stride) float32; the first hop*(n_frames[b]-1) samples
+ *                of row b are written, the rest of the row is zero-filled.
+ *   sc_curve_dev NULL, or (batch, n_iter) float32 receiving the spectral
+ *                convergence || |stft(istft(angles_k))| - |S| || / ||S|| of every
+ *                iteration.
+ */
+int glv_griffinlim(glv_plan* plan, const float* S_dev, const float* phase0_dev, uint64_t seed,
+                   const int* n_frames_host, int batch, int frames_stride, int n_iter,
+                   float momentum, float* y_dev, int64_t y_stride, float* sc_curve_dev,
+                   void* stream);
+
+/*
+ * audio / (max|audio| + eps) per utterance (reference vocoder/mel_audio.py:129,
+ * eps = 1e-6).  In place on y_dev rows of n_samples_host[b] samples.
+ */
+int glv_peak_normalize(glv_plan* plan, float* y_dev, const int* n_samples_host, int batch,
+                       int64_t y_stride, float eps, void* stream);
+
+/*
+ * librosa.stft / librosa.istft with the plan's n_fft, hop and window, exposed
+ * for stage-wise checks of the two transforms inside librosa.griffinlim
+ * (reference vocoder/mel_audio.py:126).
+ *   glv_stft : y_dev (batch, y_stride), hop*(n_frames[b]-1) samples used per row
+ *              -> D_dev (batch, frames_stride, F) interleaved complex64.
+ *   glv_istft: D_dev -> y_dev, same shapes.
+ */
+int glv_stft(glv_plan* plan, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+             int batch, int frames_stride, float* D_dev, void* stream);
+int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int batch,
+              int frames_stride, float* y_dev, int64_t y_stride, void* stream);
+
+/*
+ * Tuning and measurement hooks (no counterpart in the reference).
+ *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks),
+ *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
+ *                        "timing" (0/1: bracket the iteration loop with hipEvents).
+ *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration
+ *                        kernels of the last glv_griffinlim call took on the
+ *                        stream (synchronises on the closing event).
+ */
+int glv_plan_set_option(glv_plan* plan, const char* name, int value);
+int glv_plan_last_loop_ms(glv_plan* plan, float* ms_out);
+
+const char* glv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLVOC_H */

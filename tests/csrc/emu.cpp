@@ -1,0 +1,238 @@
+// CPU emulation of the wave engine (tts_amd/csrc/engine.h): the 64 lanes of a
+// wavefront become a loop, LDS becomes two alternating host buffers, a kernel
+// launch becomes a loop over runs.  TEST INFRASTRUCTURE: it exists so the index
+// algebra, the run/tail bookkeeping and the numerics of the exact code the GPU
+// executes can be checked against the oracle on a machine without a GPU.  It is
+// built by tests/conftest.py into tests/csrc/libglvemu.so and is not part of the
+// product library.
+#include <stdint.h>
+#include <string.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../tts_amd/csrc/elementwise.h"
+#include "../../tts_amd/csrc/engine.h"
+#include "../../tts_amd/csrc/host_tables.h"
+
+using namespace glv;
+
+namespace {
+
+template <int A, int HB, int MODE, bool SC>
+void emu_launch(const IterArgs& a) {
+    using Eng = Engine<A, HB>;
+    using G = Geo<A>;
+    std::vector<cf> b0(G::XBUF), b1(G::XBUF);
+    std::vector<Eng> e(64);
+    for (int ri = 0; ri < a.n_runs; ++ri) {
+        const RunDesc run = a.runs[ri];
+        for (int l = 0; l < 64; ++l) e[l].init(a, a.tables, l, run);
+        if (MODE != MODE_ISTFT)
+            for (int l = 0; l < 64; ++l) e[l].preload(a);
+        for (int t = run.t_begin; t < run.t_end; ++t) {
+            if (MODE != MODE_ISTFT) {
+                for (int l = 0; l < 64; ++l) e[l].ph0(a, t, b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
+                if (MODE == MODE_STFT) {
+                    for (int l = 0; l < 64; ++l) e[l].ph3_stft(a, t, b0.data());
+                    continue;
+                }
+                for (int l = 0; l < 64; ++l) e[l].template ph3_update<SC>(a, t, b0.data());
+            } else {
+                for (int l = 0; l < 64; ++l) e[l].ph3_load(a, t);
+            }
+            for (int l = 0; l < 64; ++l) e[l].ph3_write(b1.data());
+            for (int l = 0; l < 64; ++l) e[l].ph4(b1.data(), b0.data());
+            for (int l = 0; l < 64; ++l) e[l].ph5_read(b0.data());
+            for (int l = 0; l < 64; ++l) e[l].ph5_write(b1.data());
+            for (int l = 0; l < 64; ++l) e[l].ph6(a, t, b1.data());
+        }
+        if (MODE != MODE_STFT)
+            for (int l = 0; l < 64; ++l) e[l].flush_tails(a);
+        if (SC && a.sc_partial) {
+            float num = 0.f, den = 0.f;
+            for (int l = 0; l < 64; ++l) {
+                num += e[l].sc_num;
+                den += e[l].sc_den;
+            }
+            a.sc_partial[2 * ri] = num;
+            a.sc_partial[2 * ri + 1] = den;
+        }
+    }
+}
+
+struct Shape {
+    int n_fft, hop, win_length;
+};
+
+template <int A, int HB>
+struct Emu {
+    using G = Geo<A>;
+    static constexpr int R = G::E / HB, H = 128 * HB, P = G::P, F = G::P + 1;
+
+    HostTables tab;
+    std::vector<RunDesc> runs;
+    std::vector<unsigned char> flags;
+    std::vector<cf> spec;
+    std::vector<float> S_native, ym[2], yt[2], sc_partial;
+    std::vector<int> nf;
+    int batch, Ts, blocks;
+    LayoutArgs L;
+    IterArgs a;
+
+    Emu(const Shape& s, const int* n_frames, int batch_, int frames_stride, int frames_per_run)
+        : batch(batch_), Ts(frames_stride) {
+        tab = build_tables<A>(s.hop, s.win_length);
+        nf.assign(n_frames, n_frames + batch);
+        runs = build_runs(n_frames, batch, frames_per_run, R);
+        blocks = Ts + R;
+        flags = build_tail_flags(runs, batch, blocks, R);
+        spec.assign((size_t)batch * Ts * P, cf{0, 0});
+        S_native.assign((size_t)batch * Ts * (P + 4), 0.f);
+        for (int i = 0; i < 2; ++i) {
+            ym[i].assign((size_t)batch * blocks * H, 0.f);
+            yt[i].assign((size_t)batch * blocks * H, 0.f);
+        }
+        sc_partial.assign(2 * runs.size(), 0.f);
+        L = LayoutArgs{s.n_fft, s.hop, F, P, R, Ts, (int64_t)blocks * H, nf.data()};
+        memset(&a, 0, sizeof(a));
+        a.runs = runs.data();
+        a.n_runs = (int)runs.size();
+        a.spec = spec.data();
+        a.S = S_native.data();
+        a.spec_utt_stride = (int64_t)Ts * P;
+        a.s_utt_stride = (int64_t)Ts * (P + 4);
+        a.y_utt_stride = (int64_t)blocks * H;
+        a.w2 = tab.w2.data();
+        a.iwss = tab.iwss.data();
+        a.tables = tab.fft.data();
+        a.inv_n = 1.0f / s.n_fft;
+    }
+    void io(int in, int out) {
+        a.y_in = ym[in].data();
+        a.y_in_tail = yt[in].data();
+        a.y_out = ym[out].data();
+        a.y_out_tail = yt[out].data();
+    }
+    void finalize(int buf, float* y, int64_t y_stride) {
+        for (int b = 0; b < batch; ++b)
+            for (int64_t n = 0; n < y_stride; ++n)
+                finalize_sample(L, ym[buf].data(), yt[buf].data(), flags.data(), blocks, tab.w2.data(),
+                                tab.iwss.data(), y, y_stride, b, n);
+    }
+
+    int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
+                   float* y, int64_t y_stride, float* sc) {
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < nf[b]; ++t)
+                for (int q = 0; q < P; ++q)
+                    init_native_element<A>(L, S, reinterpret_cast<const cf*>(phase0), seed, a.inv_n,
+                                           S_native.data(), spec.data(), b, t, q);
+        a.cmom = momentum / (1.0f + momentum);
+        a.raw_in = 0;
+        io(1, 0);
+        emu_launch<A, HB, MODE_ISTFT, false>(a);
+        int cur = 0;
+        for (int k = 0; k < n_iter; ++k) {
+            a.has_prev = k > 0;
+            a.sc_partial = sc ? sc_partial.data() : nullptr;
+            io(cur, cur ^ 1);
+            if (sc)
+                emu_launch<A, HB, MODE_ITER, true>(a);
+            else
+                emu_launch<A, HB, MODE_ITER, false>(a);
+            cur ^= 1;
+            if (sc) {
+                for (int b = 0; b < batch; ++b) {
+                    double num = 0, den = 0;
+                    for (size_t r = 0; r < runs.size(); ++r)
+                        if (runs[r].utt == b) {
+                            num += sc_partial[2 * r];
+                            den += sc_partial[2 * r + 1];
+                        }
+                    sc[(size_t)b * n_iter + k] = (float)std::sqrt(num / den);
+                }
+            }
+        }
+        finalize(cur, y, y_stride);
+        return 0;
+    }
+
+    int stft(const float* y, int64_t y_stride, float* D) {
+        for (int b = 0; b < batch; ++b) {
+            const int64_t len = (int64_t)H * (nf[b] - 1);
+            for (int64_t n = 0; n < len; ++n)
+                ym[0][(size_t)b * a.y_utt_stride + s_nfft() / 2 + n] = y[(size_t)b * y_stride + n];
+        }
+        a.raw_in = 1;
+        io(0, 1);
+        emu_launch<A, HB, MODE_STFT, false>(a);
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < nf[b]; ++t)
+                for (int q = 0; q < P; ++q)
+                    spec_to_natural_element<A>(L, spec.data(), reinterpret_cast<cf*>(D), b, t, q);
+        return 0;
+    }
+    int istft(const float* D, float* y, int64_t y_stride) {
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < nf[b]; ++t)
+                for (int q = 0; q < P; ++q)
+                    spec_to_native_element<A>(L, reinterpret_cast<const cf*>(D), a.inv_n, spec.data(), b, t, q);
+        a.raw_in = 0;
+        io(1, 0);
+        emu_launch<A, HB, MODE_ISTFT, false>(a);
+        finalize(0, y, y_stride);
+        return 0;
+    }
+    static int s_nfft() { return G::N; }
+};
+
+template <typename Fn>
+int dispatch(int n_fft, int hop, Fn&& fn) {
+    const int hb = hop / 128;
+    if (hop % 128 != 0) return -2;
+    if (n_fft == 1024 && hb == 1) return fn((Emu<1, 1>*)nullptr);
+    if (n_fft == 1024 && hb == 2) return fn((Emu<1, 2>*)nullptr);
+    if (n_fft == 1024 && hb == 4) return fn((Emu<1, 4>*)nullptr);
+    if (n_fft == 2048 && hb == 1) return fn((Emu<2, 1>*)nullptr);
+    if (n_fft == 2048 && hb == 2) return fn((Emu<2, 2>*)nullptr);
+    if (n_fft == 2048 && hb == 4) return fn((Emu<2, 4>*)nullptr);
+    return -2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const float* phase0,
+                   uint64_t seed, const int* n_frames, int batch, int frames_stride, int n_iter,
+                   float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc) {
+    return dispatch(n_fft, hop, [&](auto* tag) {
+        using E = std::remove_pointer_t<decltype(tag)>;
+        E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
+        return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
+    });
+}
+
+int emu_stft(int n_fft, int hop, int win_length, const float* y, int64_t y_stride, const int* n_frames,
+             int batch, int frames_stride, int frames_per_run, float* D) {
+    return dispatch(n_fft, hop, [&](auto* tag) {
+        using E = std::remove_pointer_t<decltype(tag)>;
+        E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
+        return e.stft(y, y_stride, D);
+    });
+}
+
+int emu_istft(int n_fft, int hop, int win_length, const float* D, const int* n_frames, int batch,
+              int frames_stride, int frames_per_run, float* y, int64_t y_stride) {
+    return dispatch(n_fft, hop, [&](auto* tag) {
+        using E = std::remove_pointer_t<decltype(tag)>;
+        E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
+        return e.istft(D, y, y_stride);
+    });
+}
+}

@@ -1,0 +1,107 @@
+// Element-wise stages around the wave engine, one output element per call.
+// Device kernels (glvoc.hip) and the host emulation (tests/csrc) both loop over
+// these functions.
+#pragma once
+
+#include "engine.h"
+
+namespace glv {
+
+struct LayoutArgs {
+    int n_fft, hop, F, P, R;
+    int frames_stride;        // frames per utterance row in caller arrays and in spec/S
+    int64_t y_utt_stride;     // floats per utterance in the padded overlap-add buffers
+    const int* n_frames;      // [batch]
+};
+
+// --- natural (B, T, F) arrays -> native state for the iteration -------------
+// One call per (utterance b, frame t, native position q).  angles = phase * S is
+// stored pre-scaled by 1/n_fft (the inverse transform is unnormalised).
+template <int A>
+GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const cf* phase_nat,
+                                uint64_t seed, float inv_n, float* S_native, cf* spec, int b, int t,
+                                int q) {
+    const int reg = q >> 6, lane = q & 63;
+    const int k = Geo<A>::bin(reg, lane);
+    const int64_t fr = (int64_t)b * L.frames_stride + t;
+    const float* srow = S_nat + fr * L.F;
+    float* snat = S_native + fr * (L.P + 4);
+    const float s = srow[k];
+    snat[native_s_index(reg, lane)] = s;
+    auto phase_at = [&](int kk) -> cf {
+        if (phase_nat) return phase_nat[fr * L.F + kk];
+        const float u = counter_uniform(seed, (uint64_t)(fr * L.F + kk));
+        const float ph = 6.28318530717958647692f * u;
+        return cf{cosf(ph), sinf(ph)};
+    };
+    const cf p = phase_at(k);
+    cf ang = cf{p.x * s * inv_n, p.y * s * inv_n};
+    if (q == 0) {
+        const float s_nyq = srow[L.P];
+        snat[L.P] = s_nyq;
+        snat[L.P + 1] = snat[L.P + 2] = snat[L.P + 3] = 0.f;
+        const cf pn = phase_at(L.P);
+        ang = cf{p.x * s * inv_n, pn.x * s_nyq * inv_n};  // c2r ignores Im of DC / Nyquist
+    }
+    spec[fr * L.P + native_spec_index(reg, lane)] = ang;
+}
+
+// natural complex spectrum -> native (for glv_istft), scaled by 1/n_fft
+template <int A>
+GLV_HD void spec_to_native_element(const LayoutArgs& L, const cf* D_nat, float inv_n, cf* spec, int b,
+                                   int t, int q) {
+    const int reg = q >> 6, lane = q & 63;
+    const int k = Geo<A>::bin(reg, lane);
+    const int64_t fr = (int64_t)b * L.frames_stride + t;
+    cf d = D_nat[fr * L.F + k];
+    if (q == 0) d = cf{d.x, D_nat[fr * L.F + L.P].x};
+    spec[fr * L.P + native_spec_index(reg, lane)] = cf{d.x * inv_n, d.y * inv_n};
+}
+
+// native -> natural complex spectrum (for glv_stft)
+template <int A>
+GLV_HD void spec_to_natural_element(const LayoutArgs& L, const cf* spec, cf* D_nat, int b, int t, int q) {
+    const int reg = q >> 6, lane = q & 63;
+    const int k = Geo<A>::bin(reg, lane);
+    const int64_t fr = (int64_t)b * L.frames_stride + t;
+    const cf d = spec[fr * L.P + native_spec_index(reg, lane)];
+    if (q == 0) {
+        D_nat[fr * L.F] = cf{d.x, 0.f};
+        D_nat[fr * L.F + L.P] = cf{d.y, 0.f};
+    } else {
+        D_nat[fr * L.F + k] = d;
+    }
+}
+
+// --- finished overlap-add sums -> output waveform ---------------------------
+// out[b][n] for n < y_stride; returns |value| for the peak search.
+GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const float* y_tail,
+                             const unsigned char* tail_flag, int blocks_stride, const float* w2,
+                             const float* iwss, float* out, int64_t out_stride, int b, int64_t n) {
+    const int T = L.n_frames[b];
+    const int64_t len = (int64_t)L.hop * (T - 1);
+    float val = 0.f;
+    if (n < len) {
+        const int64_t p = n + L.n_fft / 2;
+        const int j = (int)(p / L.hop), s = (int)(p % L.hop);
+        const int64_t at = (int64_t)b * L.y_utt_stride + p;
+        if (j < T) val = y_main[at];
+        if (tail_flag[(int64_t)b * blocks_stride + j]) val += y_tail[at];
+        float iw;
+        if (j >= L.R - 1 && j <= T - 1) {
+            iw = iwss[s];
+        } else {
+            int t0 = j - L.R + 1;
+            if (t0 < 0) t0 = 0;
+            const int t1 = j < T - 1 ? j : T - 1;
+            float sum = 0.f;
+            for (int t = t0; t <= t1; ++t) sum += w2[(j - t) * L.hop + s];
+            iw = sum > 1.17549435e-38f ? 1.0f / sum : 1.0f;
+        }
+        val *= iw;
+    }
+    out[(int64_t)b * out_stride + n] = val;
+    return fabsf(val);
+}
+
+}  // namespace glv

@@ -1,0 +1,319 @@
+// Per-wavefront Griffin-Lim engine: one wave walks a run of consecutive frames of
+// one utterance and, per frame, performs
+//     STFT frame -> momentum phase update -> inverse FFT -> overlap-add
+// entirely in registers (plus the wave-private LDS exchanges of wave_fft.h).
+//
+// Overlap-add without atomics or barriers: consecutive frames overlap by
+// N - H samples, so the wave keeps the N-sample running sum in registers
+// (`acc`), adds each windowed frame, emits the H oldest samples (now complete)
+// and shifts by H.  H = 128*HB samples is exactly HB registers per lane, so the
+// shift is register renaming.  The same trick slides the STFT input (`raw`).
+//
+// Run boundaries: the first R-1 blocks a run emits lack the contributions of
+// the previous run's last frames ("heads"); the R-1 blocks left in `acc`
+// after a run's last frame lack those of the next run ("tails").  Heads go to
+// the main buffer like complete blocks, tails to a second buffer, and whoever
+// reads a boundary block adds the two.  Division by the window-sum-square
+// happens at read time.  Buffers are indexed in padded coordinates:
+// block j = samples [j*H, (j+1)*H) of the N + H*(T-1) sample overlap-add line;
+// the signal proper is blocks [R/2, R/2 + T-1).
+//
+// Everything here compiles for the host as well (lanes become a loop in
+// tests/csrc), see wave_fft.h.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "wave_fft.h"
+
+namespace glv {
+
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+struct RunDesc {
+    int utt, t_begin, t_end, n_frames;
+};
+
+enum Mode { MODE_ITER = 0, MODE_ISTFT = 1, MODE_STFT = 2 };
+
+struct IterArgs {
+    const RunDesc* runs;
+    int n_runs;
+    cf* spec;                 // native spectra: tprev / angles, [utt][frame][P]
+    const float* S;           // native target magnitudes, [utt][frame][P+4] (Nyquist at [P])
+    const float* y_in;        // previous overlap-add sums (or padded signal if raw_in)
+    const float* y_in_tail;
+    float* y_out;
+    float* y_out_tail;
+    int64_t spec_utt_stride;  // cf units
+    int64_t s_utt_stride;     // floats
+    int64_t y_utt_stride;     // floats
+    const float* w2;          // squared window, N floats
+    const float* iwss;        // reciprocal of the complete window-sum-square, H floats
+    const cf* tables;         // twA | twB | twP | win
+    float* sc_partial;        // [run][2] (numerator, denominator) or null
+    float cmom;               // momentum / (1 + momentum)
+    float inv_n;              // 1 / n_fft
+    int has_prev;             // 0 on the first iteration (no momentum term)
+    int raw_in;               // y_in holds the padded signal itself (glv_stft)
+};
+
+GLV_HD float rcp_refined(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+
+template <int A, int HB>
+struct Engine {
+    using G = Geo<A>;
+    using F = WaveFft<A>;
+    static constexpr int E = G::E, P = G::P, N = G::N;
+    static constexpr int H = 128 * HB;  // hop
+    static constexpr int R = E / HB;    // frames covering one sample
+    static constexpr float kTiny = 1.17549435e-38f;
+
+    cf raw[E];
+    cf acc[E];
+    cf v[E];
+    cf iw[HB];
+    int mbase[A];
+    int lane;
+    RunDesc run;
+    float sc_num, sc_den;
+    Tables tab;
+
+    GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
+        lane = lane_;
+        run = r;
+        tab.twA = tables;
+        tab.twB = tab.twA + G::TW_A;
+        tab.twP = tab.twB + G::TW_B;
+        tab.win = tab.twP + G::TW_P;
+#pragma unroll
+        for (int k0a = 0; k0a < A; ++k0a) mbase[k0a] = G::mirror_base(k0a, lane);
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const cf* q = reinterpret_cast<const cf*>(a.iwss + 128 * i + 2 * lane);
+            iw[i] = *q;
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
+        sc_num = 0.f;
+        sc_den = 0.f;
+    }
+
+    // reciprocal window-sum-square of sample s of block j near an utterance edge
+    GLV_HD float edge_iwss(const IterArgs& a, int j, int s) const {
+        const int T = run.n_frames;
+        int t0 = j - R + 1;
+        if (t0 < 0) t0 = 0;
+        int t1 = j < T - 1 ? j : T - 1;
+        float sum = 0.f;
+        for (int t = t0; t <= t1; ++t) sum += a.w2[(j - t) * H + s];
+        return sum > kTiny ? 1.0f / sum : 1.0f;
+    }
+
+    // block j of the previous iteration's signal: (main + tail) / wss, zero outside
+    // the signal proper (the zero padding of a centred STFT)
+    GLV_HD void load_block(const IterArgs& a, int j, cf* out) const {
+        const int T = run.n_frames;
+        if (j < R / 2 || j >= R / 2 + T - 1) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) out[i] = cf{0.f, 0.f};
+            return;
+        }
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H + 2 * lane;
+        const bool have_main = a.raw_in || j < T;
+        const bool tail = !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
+        const bool interior = j >= R - 1 && j <= T - 1;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            cf val = cf{0.f, 0.f};
+            if (have_main) val = *reinterpret_cast<const cf*>(a.y_in + base + 128 * i);
+            if (tail) {
+                const cf tl = *reinterpret_cast<const cf*>(a.y_in_tail + base + 128 * i);
+                val = val + tl;
+            }
+            if (!a.raw_in) {
+                cf w = iw[i];
+                if (!interior) {
+                    w.x = edge_iwss(a, j, 128 * i + 2 * lane);
+                    w.y = edge_iwss(a, j, 128 * i + 2 * lane + 1);
+                }
+                val.x *= w.x;
+                val.y *= w.y;
+            }
+            out[i] = val;
+        }
+    }
+
+    GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf* src) const {
+        const int T = run.n_frames;
+        if (j < R / 2 || j >= R / 2 + T - 1) return;
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H + 2 * lane;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) *reinterpret_cast<cf*>(dst + base + 128 * i) = src[i];
+    }
+
+    // blocks t_begin .. t_begin+R-2 of the first frame
+    GLV_HD void preload(const IterArgs& a) {
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) load_block(a, run.t_begin + q, &raw[q * HB]);
+    }
+
+    // ---- phase 0: newest block, window, first DFT pass ----
+    GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
+        load_block(a, t + R - 1, &raw[(R - 1) * HB]);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const cf wn = tab.win[r * 64 + lane];
+            v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
+        }
+#pragma unroll
+        for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
+        F::fwd_a(v, tab, w, lane);
+    }
+    GLV_HD void ph1_read(const cf* r) { F::fwd_b(v, tab, r, lane); }
+    GLV_HD void ph1_write(cf* w) { F::fwd_b_store(v, w, lane); }
+    GLV_HD void ph2_read(const cf* r) { F::fwd_c(v, r, lane); }
+    GLV_HD void ph2_write(cf* w) { F::mirror_store(v, w, lane); }
+
+    GLV_HD cf* spec_frame(const IterArgs& a, int t) const {
+        return a.spec + (int64_t)run.utt * a.spec_utt_stride + (int64_t)t * P;
+    }
+
+    // ---- phase 3 (STFT only): finish the split and store the frame ----
+    GLV_HD void ph3_stft(const IterArgs& a, int t, const cf* r) {
+        cf m[E];
+        F::mirror_load(m, r, mbase);
+        F::split_fwd(v, m, tab, lane);
+        store_spec(a, t);
+    }
+    GLV_HD void store_spec(const IterArgs& a, int t) {
+        f4* sp = reinterpret_cast<f4*>(spec_frame(a, t));
+#pragma unroll
+        for (int pq = 0; pq < E / 2; ++pq)
+            sp[pq * 64 + lane] = f4{v[2 * pq].x, v[2 * pq].y, v[2 * pq + 1].x, v[2 * pq + 1].y};
+    }
+    GLV_HD void load_spec(const IterArgs& a, int t, cf (&dst)[E]) const {
+        const f4* sp = reinterpret_cast<const f4*>(spec_frame(a, t));
+#pragma unroll
+        for (int pq = 0; pq < E / 2; ++pq) {
+            const f4 q = sp[pq * 64 + lane];
+            dst[2 * pq] = cf{q.x, q.y};
+            dst[2 * pq + 1] = cf{q.z, q.w};
+        }
+    }
+
+    // ---- phase 3 (iteration): rebuilt spectrum, momentum phase update ----
+    // librosa.griffinlim loop body after the stft: angles = rebuilt - c*tprev;
+    // angles /= |angles| + tiny; angles *= S; tprev = rebuilt.
+    template <bool SC>
+    GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
+        cf m[E];
+        F::mirror_load(m, r, mbase);
+        F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
+        cf tp[E];
+        if (a.has_prev) load_spec(a, t, tp);
+        float s[E];
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const f4 sq = reinterpret_cast<const f4*>(sf)[q * 64 + lane];
+            s[4 * q] = sq.x;
+            s[4 * q + 1] = sq.y;
+            s[4 * q + 2] = sq.z;
+            s[4 * q + 3] = sq.w;
+        }
+        const float s_nyq = sf[P];
+        store_spec(a, t);
+#pragma unroll
+        for (int reg = 0; reg < E; ++reg) {
+            const cf x = v[reg];
+            const bool packed = (reg == 0) && (lane == 0);
+            const float sx = s[reg], sy = packed ? s_nyq : s[reg];
+            if (SC) {
+                const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                const float ex = (packed ? fabsf(x.x) : mag) - fabsf(sx);
+                const float ey = packed ? fabsf(x.y) - fabsf(sy) : 0.f;
+                sc_num += ex * ex + ey * ey;
+                sc_den += sx * sx + (packed ? sy * sy : 0.f);
+            }
+            cf d = x;
+            if (a.has_prev) d = cf{x.x - a.cmom * tp[reg].x, x.y - a.cmom * tp[reg].y};
+            const float mag = sqrtf(d.x * d.x + d.y * d.y);
+            const float mx = packed ? fabsf(d.x) : mag;
+            const float my = packed ? fabsf(d.y) : mag;
+            const float ix = rcp_refined(mx + kTiny) * a.inv_n;
+            const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
+            v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
+        }
+    }
+    // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
+    GLV_HD void ph3_load(const IterArgs& a, int t) { load_spec(a, t, v); }
+
+    GLV_HD void ph3_write(cf* w) { F::mirror_store(v, w, lane); }
+
+    GLV_HD void ph4(const cf* r, cf* w) {
+        cf m[E];
+        F::mirror_load(m, r, mbase);
+        F::split_inv(v, m, tab, lane);
+        F::inv_c(v, w, lane);
+    }
+    GLV_HD void ph5_read(const cf* r) { F::inv_b(v, tab, r, lane); }
+    GLV_HD void ph5_write(cf* w) { F::inv_b_store(v, w, lane); }
+
+    // ---- phase 6: last inverse pass, window, overlap-add, emit block t ----
+    GLV_HD void ph6(const IterArgs& a, int t, const cf* r) {
+        F::inv_a(v, tab, r, lane);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const cf wn = tab.win[q * 64 + lane];
+            acc[q].x = fmaf(v[q].x, wn.x, acc[q].x);
+            acc[q].y = fmaf(v[q].y, wn.y, acc[q].y);
+        }
+        store_block(a, a.y_out, t, &acc[0]);
+#pragma unroll
+        for (int q = 0; q + HB < E; ++q) acc[q] = acc[q + HB];
+#pragma unroll
+        for (int q = E - HB; q < E; ++q) acc[q] = cf{0.f, 0.f};
+    }
+    // what is left after the last frame belongs to blocks t_end .. t_end+R-2
+    GLV_HD void flush_tails(const IterArgs& a) {
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out_tail, run.t_end + q, &acc[q * HB]);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Element-wise helpers shared by the device kernels and the host emulation.
+// ---------------------------------------------------------------------------
+
+// (position in native order) -> natural bin, for position q = reg*64 + lane
+template <int A>
+GLV_HD int native_bin(int q) {
+    return Geo<A>::bin(q >> 6, q & 63);
+}
+
+// index of (reg, lane) inside a native spectrum frame (cf units) and S frame (floats)
+GLV_HD int native_spec_index(int reg, int lane) { return ((reg >> 1) * 64 + lane) * 2 + (reg & 1); }
+GLV_HD int native_s_index(int reg, int lane) { return ((reg >> 2) * 64 + lane) * 4 + (reg & 3); }
+
+// uniform [0,1) from a counter (splitmix64 finaliser); the device-side stand-in
+// for librosa's unseeded default_rng when the caller supplies no phase
+GLV_HD float counter_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace glv

@@ -1,0 +1,111 @@
+// Host-side builders shared by libglvoc and the CPU emulation used in tests:
+// window / twiddle tables, window-sum-square reciprocals and the run table that
+// maps wavefronts to frame ranges.
+#pragma once
+
+#include <float.h>
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+
+namespace glv {
+
+struct HostTables {
+    std::vector<cf> fft;      // twA | twB | twP | win   (Geo<A>::TABLES)
+    std::vector<float> w2;    // squared window, N
+    std::vector<float> iwss;  // reciprocal complete window-sum-square, H
+};
+
+// Periodic Hann window of win_length, zero-padded centrally to n_fft
+// (scipy.signal.get_window('hann', win_length, fftbins=True) + librosa.util.pad_center).
+inline std::vector<double> padded_hann(int n_fft, int win_length) {
+    std::vector<double> w(n_fft, 0.0);
+    const int lpad = (n_fft - win_length) / 2;
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < win_length; ++n) w[lpad + n] = 0.5 - 0.5 * cos(2.0 * pi * n / win_length);
+    return w;
+}
+
+template <int A>
+HostTables build_tables(int hop, int win_length) {
+    using G = Geo<A>;
+    const double pi = 3.14159265358979323846;
+    HostTables t;
+    t.fft.resize(G::TABLES);
+    cf* twA = t.fft.data();
+    cf* twB = twA + G::TW_A;
+    cf* twP = twB + G::TW_B;
+    cf* win = twP + G::TW_P;
+    for (int k0 = 1; k0 < G::E; ++k0)
+        for (int lane = 0; lane < 64; ++lane) {
+            const double th = 2.0 * pi * (double)(k0 * lane) / G::P;
+            twA[(k0 - 1) * 64 + lane] = cf{(float)cos(th), (float)-sin(th)};
+        }
+    for (int k1 = 1; k1 < 8; ++k1)
+        for (int n0 = 0; n0 < 8; ++n0) {
+            const double th = 2.0 * pi * (double)(k1 * n0) / 64.0;
+            twB[(k1 - 1) * 8 + n0] = cf{(float)cos(th), (float)-sin(th)};
+        }
+    for (int reg = 0; reg < G::E; ++reg)
+        for (int lane = 0; lane < 64; ++lane) {
+            const double th = 2.0 * pi * (double)G::bin(reg, lane) / G::N;
+            twP[reg * 64 + lane] = cf{(float)(0.5 * cos(th)), (float)(-0.5 * sin(th))};
+        }
+    const std::vector<double> w = padded_hann(G::N, win_length);
+    for (int reg = 0; reg < G::E; ++reg)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = 64 * reg + lane;
+            win[reg * 64 + lane] = cf{(float)w[2 * m], (float)w[2 * m + 1]};
+        }
+    t.w2.resize(G::N);
+    for (int n = 0; n < G::N; ++n) t.w2[n] = (float)(w[n] * w[n]);
+    // librosa.filters.window_sumsquare accumulates float64 squares into a float32
+    // line, one frame after the other; a fully covered sample sees the frames in
+    // ascending order, i.e. window offsets in descending order.
+    const int R = G::N / hop;
+    t.iwss.resize(hop);
+    for (int s = 0; s < hop; ++s) {
+        float acc = 0.f;
+        for (int u = R - 1; u >= 0; --u) acc = (float)((double)acc + w[u * hop + s] * w[u * hop + s]);
+        t.iwss[s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
+    }
+    return t;
+}
+
+// Splits every utterance into runs of about frames_per_run consecutive frames.
+// A run is never shorter than R-1 frames (unless it is the whole utterance), so
+// the tail blocks of one run fall inside the head blocks of the next.
+inline std::vector<RunDesc> build_runs(const int* n_frames, int batch, int frames_per_run, int R) {
+    std::vector<RunDesc> runs;
+    for (int b = 0; b < batch; ++b) {
+        const int T = n_frames[b];
+        if (T <= 0) continue;
+        int nr = (T + frames_per_run / 2) / std::max(1, frames_per_run);
+        const int min_len = std::max(1, R - 1);
+        nr = std::max(1, std::min(nr, T / min_len));
+        for (int i = 0; i < nr; ++i) {
+            const int t0 = (int)((int64_t)i * T / nr), t1 = (int)((int64_t)(i + 1) * T / nr);
+            runs.push_back(RunDesc{b, t0, t1, T});
+        }
+    }
+    return runs;
+}
+
+// tail_flag[b*blocks_stride + j] = 1 when block j of utterance b is completed by
+// adding the tail buffer (first R-1 blocks after an interior run boundary, and
+// the R-1 blocks past the last frame).
+inline std::vector<unsigned char> build_tail_flags(const std::vector<RunDesc>& runs, int batch,
+                                                   int blocks_stride, int R) {
+    std::vector<unsigned char> f((size_t)batch * blocks_stride, 0);
+    for (const RunDesc& r : runs)
+        for (int q = 0; q < R - 1; ++q) {
+            const int j = r.t_end + q;
+            if (j < blocks_stride) f[(size_t)r.utt * blocks_stride + j] = 1;
+        }
+    return f;
+}
+
+}  // namespace glv
