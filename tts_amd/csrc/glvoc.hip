@@ -1,0 +1,834 @@
+// libglvoc: HIP kernels (gfx950) and the C ABI declared in include/glvoc.h.
+//
+// Kernel inventory
+//   gl_engine_kernel   one wavefront per run of frames: STFT frame -> phase update ->
+//                      inverse FFT -> register overlap-add (engine.h).  Modes: full
+//                      iteration, iSTFT only, STFT only.  HBM-bound by design:
+//                      per frame it reads tprev (8P B) + S (4P B) + H new samples and
+//                      writes tprev (8P B) + H samples.
+//   mel_invert_kernel  dB -> power fused into an f32 MFMA GEMM with the inverse basis.
+//   init/convert/finalize/peak/sc kernels: element-wise stages (elementwise.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/glvoc.h"
+#include "elementwise.h"
+#include "engine.h"
+#include "host_tables.h"
+
+using namespace glv;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(GLV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" const char* glv_last_error(void) { return g_err; }
+extern "C" int glv_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------
+// device code
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ void wave_sync() {
+    // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
+    // One wave's DS operations execute in issue order, so no counter wait is needed;
+    // the fences only pin the compiler.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int A, int HB, int MODE, bool SC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void gl_engine_kernel(IterArgs a) {
+    using G = Geo<A>;
+    using Eng = Engine<A, HB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* tables = reinterpret_cast<cf*>(smem);
+    for (int i = threadIdx.x; i < G::TABLES; i += blockDim.x) tables[i] = a.tables[i];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ri = blockIdx.x * kWavesPerBlock + wave;
+    if (ri >= a.n_runs) return;
+    cf* xb = tables + G::TABLES + wave * G::XBUF;
+
+    Eng e;
+    e.init(a, tables, lane, a.runs[ri]);
+    if (MODE != MODE_ISTFT) e.preload(a);
+    for (int t = e.run.t_begin; t < e.run.t_end; ++t) {
+        if (MODE != MODE_ISTFT) {
+            e.ph0(a, t, xb);
+            wave_sync();
+            e.ph1_read(xb);
+            wave_sync();
+            e.ph1_write(xb);
+            wave_sync();
+            e.ph2_read(xb);
+            wave_sync();
+            e.ph2_write(xb);
+            wave_sync();
+            if (MODE == MODE_STFT) {
+                e.ph3_stft(a, t, xb);
+                wave_sync();
+                continue;
+            }
+            e.template ph3_update<SC>(a, t, xb);
+        } else {
+            e.ph3_load(a, t);
+        }
+        wave_sync();
+        e.ph3_write(xb);
+        wave_sync();
+        e.ph4(xb, xb);
+        wave_sync();
+        e.ph5_read(xb);
+        wave_sync();
+        e.ph5_write(xb);
+        wave_sync();
+        e.ph6(a, t, xb);
+        wave_sync();
+    }
+    if (MODE != MODE_STFT) e.flush_tails(a);
+    if (SC) {
+        float num = e.sc_num, den = e.sc_den;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            num += __shfl_xor(num, off);
+            den += __shfl_xor(den, off);
+        }
+        if (lane == 0 && a.sc_partial) {
+            a.sc_partial[2 * ri] = num;
+            a.sc_partial[2 * ri + 1] = den;
+        }
+    }
+}
+
+struct ElemArgs {
+    LayoutArgs L;
+    int batch;
+};
+
+template <int A>
+__global__ void init_native_kernel(ElemArgs ea, const float* S_nat, const cf* phase_nat, uint64_t seed,
+                                   float inv_n, float* S_native, cf* spec) {
+    const int P = ea.L.P;
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % P);
+        const int64_t fr = i / P;
+        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
+        if (t < ea.L.n_frames[b])
+            init_native_element<A>(ea.L, S_nat, phase_nat, seed, inv_n, S_native, spec, b, t, q);
+    }
+}
+
+template <int A, bool TO_NATIVE>
+__global__ void spec_convert_kernel(ElemArgs ea, const cf* src, float inv_n, cf* dst) {
+    const int P = ea.L.P;
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % P);
+        const int64_t fr = i / P;
+        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
+        if (t >= ea.L.n_frames[b]) continue;
+        if (TO_NATIVE)
+            spec_to_native_element<A>(ea.L, src, inv_n, dst, b, t, q);
+        else
+            spec_to_natural_element<A>(ea.L, src, dst, b, t, q);
+    }
+}
+
+// caller signal (B, y_stride) -> padded overlap-add coordinates, offset n_fft/2
+__global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride, float* ypad) {
+    const int b = blockIdx.y;
+    const int64_t len = (int64_t)ea.L.hop * (ea.L.n_frames[b] - 1);
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
+         n += (int64_t)gridDim.x * blockDim.x)
+        ypad[(int64_t)b * ea.L.y_utt_stride + ea.L.n_fft / 2 + n] = y[(int64_t)b * y_stride + n];
+}
+
+__global__ void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
+                                const unsigned char* tail_flag, int blocks_stride, const float* w2,
+                                const float* iwss, float* out, int64_t out_stride) {
+    const int b = blockIdx.y;
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
+         n += (int64_t)gridDim.x * blockDim.x)
+        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, out, out_stride, b, n);
+}
+
+__global__ void peak_reduce_kernel(const float* y, int64_t y_stride, const int* n_samples,
+                                   unsigned* peak_bits) {
+    const int b = blockIdx.y;
+    const int64_t len = n_samples[b];
+    float m = 0.f;
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
+         n += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(y[(int64_t)b * y_stride + n]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(&peak_bits[b], __float_as_uint(m));
+}
+
+__global__ void peak_scale_kernel(float* y, int64_t y_stride, const int* n_samples,
+                                  const unsigned* peak_bits, float eps) {
+    const int b = blockIdx.y;
+    const int64_t len = n_samples[b];
+    const float denom = __uint_as_float(peak_bits[b]) + eps;
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
+         n += (int64_t)gridDim.x * blockDim.x) {
+        float* p = y + (int64_t)b * y_stride + n;
+        *p = *p / denom;
+    }
+}
+
+// sc[b][k] = sqrt(sum_runs num / sum_runs den); partials are [k][run][2]
+__global__ void sc_reduce_kernel(const float* partial, int n_runs, const int* run_off,
+                                 const int* run_cnt, int batch, int n_iter, float* sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * n_iter) return;
+    const int b = i / n_iter, k = i % n_iter;
+    float num = 0.f, den = 0.f;
+    const float* p = partial + ((int64_t)k * n_runs + run_off[b]) * 2;
+    for (int r = 0; r < run_cnt[b]; ++r) {
+        num += p[2 * r];
+        den += p[2 * r + 1];
+    }
+    sc[(int64_t)b * n_iter + k] = sqrtf(num / den);
+}
+
+// S[row][f] = sum_m pinv[f][m] * 10^(0.1*(mel[row][m]*std + mean)).
+// Block = 4 waves, tile 64 rows x 64 bins, each wave one 32x32 f32 MFMA tile;
+// the mel rows are converted to power while being staged into LDS.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMelKC = 32;  // k-chunk staged per step
+
+__global__ __launch_bounds__(256) void mel_invert_kernel(const float* __restrict__ mel,
+                                                         const float* __restrict__ pinv, int64_t rows,
+                                                         int M, int F, float mean, float std_,
+                                                         float* __restrict__ S) {
+    __shared__ float sa[64][kMelKC + 1];
+    __shared__ float sb[64][kMelKC + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row0 = (int64_t)blockIdx.y * 64;
+    const int col0 = blockIdx.x * 64;
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int m0 = 0; m0 < M; m0 += kMelKC) {
+        for (int i = threadIdx.x; i < 64 * kMelKC; i += 256) {
+            const int r = i / kMelKC, k = i % kMelKC;
+            float pa = 0.f, pb = 0.f;
+            if (m0 + k < M) {
+                if (row0 + r < rows) {
+                    // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
+                    const float x = __fadd_rn(__fmul_rn(mel[(row0 + r) * M + m0 + k], std_), mean);
+                    pa = powf(10.0f, __fmul_rn(0.1f, x));
+                }
+                if (col0 + r < F) pb = pinv[(int64_t)(col0 + r) * M + m0 + k];
+            }
+            sa[r][k] = pa;
+            sb[r][k] = pb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kMelKC; k += 2) {
+            const float av = sa[wr * 32 + (lane & 31)][k + (lane >> 5)];
+            const float bv = sb[wc * 32 + (lane & 31)][k + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = col0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row < rows && col < F) S[row * F + col] = acc[reg];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct glv_plan {
+    int n_fft, hop, win_length, n_mels, max_frames, max_batch, device;
+    int A, HB, R, P, F, blocks;  // blocks = padded H-sample blocks per utterance row
+    // options
+    int frames_per_run = 12;
+    int use_graph = 1;
+    int timing = 0;
+    // device tables
+    cf* d_tables = nullptr;
+    float* d_w2 = nullptr;
+    float* d_iwss = nullptr;
+    float* d_pinv = nullptr;
+    bool have_pinv = false;
+    // device workspace
+    cf* d_spec = nullptr;
+    float* d_S = nullptr;
+    float* d_ym[2] = {nullptr, nullptr};
+    float* d_yt[2] = {nullptr, nullptr};
+    RunDesc* d_runs = nullptr;
+    unsigned char* d_flags = nullptr;
+    int* d_nframes = nullptr;
+    int* d_nsamples = nullptr;
+    int* d_run_off = nullptr;
+    int* d_run_cnt = nullptr;
+    unsigned* d_peak = nullptr;
+    float* d_sc_partial = nullptr;
+    size_t sc_partial_cap = 0;
+    int64_t ws_bytes = 0;
+    // host mirrors of the run bookkeeping (pinned)
+    RunDesc* h_runs = nullptr;
+    unsigned char* h_flags = nullptr;
+    int* h_ints = nullptr;  // nframes | run_off | run_cnt
+    size_t max_runs = 0;
+    std::vector<int> cur_nframes;
+    int cur_frames_stride = -1, cur_fpr = -1, n_runs = 0;
+    // graph cache for the iteration loop
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        int n_runs, n_iter, with_sc, frames_stride, batch;
+        float cmom;
+        bool operator==(const GraphKey& o) const {
+            return n_runs == o.n_runs && n_iter == o.n_iter && with_sc == o.with_sc &&
+                   frames_stride == o.frames_stride && batch == o.batch && cmom == o.cmom;
+        }
+    } graph_key{};
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // kernel launchers for this shape
+    hipError_t (*launch_engine)(int mode, bool sc, const IterArgs&, size_t grid, hipStream_t) = nullptr;
+    void (*launch_init)(const ElemArgs&, const float*, const cf*, uint64_t, float, float*, cf*,
+                        hipStream_t) = nullptr;
+    void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
+};
+
+namespace {
+
+template <int A, int HB>
+hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hipStream_t st) {
+    using G = Geo<A>;
+    const size_t lds = (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf);
+    const dim3 g((unsigned)grid), b(64 * kWavesPerBlock);
+    if (mode == MODE_ITER) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ISTFT) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT, false>), g, b, lds, st, a);
+    } else {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_STFT, false>), g, b, lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+template <int A>
+void launch_init_t(const ElemArgs& ea, const float* S_nat, const cf* phase, uint64_t seed, float inv_n,
+                   float* S_native, cf* spec, hipStream_t st) {
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * ea.L.P;
+    hipLaunchKernelGGL((init_native_kernel<A>), dim3(grid_for(total, 256)), dim3(256), 0, st, ea, S_nat,
+                       phase, seed, inv_n, S_native, spec);
+}
+
+template <int A>
+void launch_convert_t(bool to_native, const ElemArgs& ea, const cf* src, float inv_n, cf* dst,
+                      hipStream_t st) {
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * ea.L.P;
+    if (to_native)
+        hipLaunchKernelGGL((spec_convert_kernel<A, true>), dim3(grid_for(total, 256)), dim3(256), 0, st,
+                           ea, src, inv_n, dst);
+    else
+        hipLaunchKernelGGL((spec_convert_kernel<A, false>), dim3(grid_for(total, 256)), dim3(256), 0, st,
+                           ea, src, inv_n, dst);
+}
+
+template <int A, int HB>
+void bind_launchers(glv_plan* p) {
+    p->launch_engine = &launch_engine_t<A, HB>;
+    p->launch_init = &launch_init_t<A>;
+    p->launch_convert = &launch_convert_t<A>;
+}
+
+template <typename T>
+hipError_t dmalloc(glv_plan* p, T** ptr, size_t count) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(ptr), bytes);
+    if (e == hipSuccess) p->ws_bytes += (int64_t)bytes;
+    return e;
+}
+
+void plan_free(glv_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    void* dev[] = {p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+                   p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_runs,    p->d_flags,
+                   p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
+    for (void* q : dev)
+        if (q) (void)hipFree(q);
+    if (p->h_runs) (void)hipHostFree(p->h_runs);
+    if (p->h_flags) (void)hipHostFree(p->h_flags);
+    if (p->h_ints) (void)hipHostFree(p->h_ints);
+    delete p;
+}
+
+ElemArgs elem_args(const glv_plan* p, int batch, int frames_stride) {
+    ElemArgs ea;
+    ea.L = LayoutArgs{p->n_fft, p->hop, p->F, p->P, p->R, frames_stride,
+                      (int64_t)p->blocks * p->hop, p->d_nframes};
+    ea.batch = batch;
+    return ea;
+}
+
+IterArgs iter_args(const glv_plan* p, int frames_stride) {
+    IterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.runs = p->d_runs;
+    a.n_runs = p->n_runs;
+    a.spec = p->d_spec;
+    a.S = p->d_S;
+    a.spec_utt_stride = (int64_t)frames_stride * p->P;
+    a.s_utt_stride = (int64_t)frames_stride * (p->P + 4);
+    a.y_utt_stride = (int64_t)p->blocks * p->hop;
+    a.w2 = p->d_w2;
+    a.iwss = p->d_iwss;
+    a.tables = p->d_tables;
+    a.inv_n = 1.0f / (float)p->n_fft;
+    return a;
+}
+
+void set_io(const glv_plan* p, IterArgs& a, int in, int out) {
+    a.y_in = p->d_ym[in];
+    a.y_in_tail = p->d_yt[in];
+    a.y_out = p->d_ym[out];
+    a.y_out_tail = p->d_yt[out];
+}
+
+// (Re)builds the run table for these lengths and uploads it.  Cached: a call with
+// the lengths of the previous call costs nothing.
+int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st) {
+    if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
+    if (batch < 1 || batch > p->max_batch)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    if (frames_stride < 1 || frames_stride > p->max_frames)
+        return fail(GLV_ERR_INVALID, "frames_stride %d outside [1, %d]", frames_stride, p->max_frames);
+    for (int b = 0; b < batch; ++b)
+        if (n_frames_host[b] < 2 || n_frames_host[b] > frames_stride)
+            return fail(GLV_ERR_INVALID, "n_frames[%d] = %d outside [2, %d]", b, n_frames_host[b],
+                        frames_stride);
+    const bool same = (int)p->cur_nframes.size() == batch && p->cur_frames_stride == frames_stride &&
+                      p->cur_fpr == p->frames_per_run &&
+                      memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
+    if (same) return GLV_OK;
+    // the pinned staging buffers may still feed an earlier call's copies
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<RunDesc> runs = build_runs(n_frames_host, batch, p->frames_per_run, p->R);
+    if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
+    std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);
+    memcpy(p->h_runs, runs.data(), runs.size() * sizeof(RunDesc));
+    memcpy(p->h_flags, flags.data(), flags.size());
+    int* nf = p->h_ints;
+    int* off = nf + p->max_batch;
+    int* cnt = off + p->max_batch;
+    for (int b = 0; b < batch; ++b) {
+        nf[b] = n_frames_host[b];
+        off[b] = 0;
+        cnt[b] = 0;
+    }
+    for (size_t r = 0; r < runs.size(); ++r) {
+        if (cnt[runs[r].utt] == 0) off[runs[r].utt] = (int)r;
+        cnt[runs[r].utt]++;
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_runs, p->h_runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_flags, p->h_flags, flags.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_nframes, nf, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_run_off, off, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_run_cnt, cnt, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+    p->cur_nframes.assign(n_frames_host, n_frames_host + batch);
+    p->cur_frames_stride = frames_stride;
+    p->cur_fpr = p->frames_per_run;
+    p->n_runs = (int)runs.size();
+    return GLV_OK;
+}
+
+size_t engine_grid(const glv_plan* p) { return (size_t)(p->n_runs + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_length, int n_mels,
+                               int max_frames, int max_batch, int device) {
+    if (!out) return fail(GLV_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_fft != 1024 && n_fft != 2048)
+        return fail(GLV_ERR_UNSUPPORTED, "n_fft %d not supported (1024 or 2048)", n_fft);
+    if (hop != 128 && hop != 256 && hop != 512)
+        return fail(GLV_ERR_UNSUPPORTED, "hop %d not supported (128, 256 or 512)", hop);
+    if (win_length < 2 || win_length > n_fft)
+        return fail(GLV_ERR_INVALID, "win_length %d outside [2, n_fft]", win_length);
+    if (n_mels < 1 || max_frames < 2 || max_batch < 1)
+        return fail(GLV_ERR_INVALID, "n_mels/max_frames/max_batch must be positive (max_frames >= 2)");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(GLV_ERR_HIP, "hipSetDevice(%d) failed", device);
+
+    glv_plan* p = new glv_plan();
+    p->n_fft = n_fft;
+    p->hop = hop;
+    p->win_length = win_length;
+    p->n_mels = n_mels;
+    p->max_frames = max_frames;
+    p->max_batch = max_batch;
+    p->device = device;
+    p->A = n_fft / 1024;
+    p->HB = hop / 128;
+    p->R = n_fft / hop;
+    p->P = n_fft / 2;
+    p->F = p->P + 1;
+    p->blocks = max_frames + p->R;
+
+    HostTables tab;
+    const int key = p->A * 10 + p->HB;
+    switch (key) {
+        case 11: tab = build_tables<1>(hop, win_length); bind_launchers<1, 1>(p); break;
+        case 12: tab = build_tables<1>(hop, win_length); bind_launchers<1, 2>(p); break;
+        case 14: tab = build_tables<1>(hop, win_length); bind_launchers<1, 4>(p); break;
+        case 21: tab = build_tables<2>(hop, win_length); bind_launchers<2, 1>(p); break;
+        case 22: tab = build_tables<2>(hop, win_length); bind_launchers<2, 2>(p); break;
+        case 24: tab = build_tables<2>(hop, win_length); bind_launchers<2, 4>(p); break;
+        default: delete p; return fail(GLV_ERR_UNSUPPORTED, "unsupported n_fft/hop pair");
+    }
+
+#define PLAN_TRY(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            plan_free(p);                                                                     \
+            return fail(GLV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                                     \
+    } while (0)
+
+    const size_t frames = (size_t)max_batch * max_frames;
+    const size_t ylen = (size_t)max_batch * p->blocks * hop;
+    p->max_runs = frames;
+    PLAN_TRY(dmalloc(p, &p->d_tables, tab.fft.size()));
+    PLAN_TRY(dmalloc(p, &p->d_w2, tab.w2.size()));
+    PLAN_TRY(dmalloc(p, &p->d_iwss, tab.iwss.size()));
+    PLAN_TRY(dmalloc(p, &p->d_pinv, (size_t)p->F * n_mels));
+    PLAN_TRY(dmalloc(p, &p->d_spec, frames * p->P));
+    PLAN_TRY(dmalloc(p, &p->d_S, frames * (p->P + 4)));
+    for (int i = 0; i < 2; ++i) {
+        PLAN_TRY(dmalloc(p, &p->d_ym[i], ylen));
+        PLAN_TRY(dmalloc(p, &p->d_yt[i], ylen));
+    }
+    PLAN_TRY(dmalloc(p, &p->d_runs, p->max_runs));
+    PLAN_TRY(dmalloc(p, &p->d_flags, (size_t)max_batch * p->blocks));
+    PLAN_TRY(dmalloc(p, &p->d_nframes, (size_t)max_batch));
+    PLAN_TRY(dmalloc(p, &p->d_nsamples, (size_t)max_batch));
+    PLAN_TRY(dmalloc(p, &p->d_run_off, (size_t)max_batch));
+    PLAN_TRY(dmalloc(p, &p->d_run_cnt, (size_t)max_batch));
+    PLAN_TRY(dmalloc(p, &p->d_peak, (size_t)max_batch));
+    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_runs), p->max_runs * sizeof(RunDesc)));
+    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_flags), (size_t)max_batch * p->blocks));
+    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_ints), sizeof(int) * 4 * max_batch));
+    PLAN_TRY(hipMemcpy(p->d_tables, tab.fft.data(), tab.fft.size() * sizeof(cf), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(p->d_w2, tab.w2.data(), tab.w2.size() * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(p->d_iwss, tab.iwss.data(), tab.iwss.size() * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipEventCreate(&p->ev0));
+    PLAN_TRY(hipEventCreate(&p->ev1));
+    PLAN_TRY(hipDeviceSynchronize());
+#undef PLAN_TRY
+    *out = p;
+    return GLV_OK;
+}
+
+extern "C" void glv_plan_destroy(glv_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    plan_free(p);
+}
+
+extern "C" int64_t glv_plan_workspace_bytes(const glv_plan* p) { return p ? p->ws_bytes : 0; }
+
+extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
+    if (!p || !name) return fail(GLV_ERR_INVALID, "null plan or option name");
+    if (!strcmp(name, "frames_per_run")) {
+        if (value < 1) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 1");
+        p->frames_per_run = value;
+    } else if (!strcmp(name, "use_graph")) {
+        p->use_graph = value != 0;
+    } else if (!strcmp(name, "timing")) {
+        p->timing = value != 0;
+    } else {
+        return fail(GLV_ERR_INVALID, "unknown option '%s'", name);
+    }
+    return GLV_OK;
+}
+
+extern "C" int glv_plan_last_loop_ms(glv_plan* p, float* ms_out) {
+    if (!p || !ms_out) return fail(GLV_ERR_INVALID, "null argument");
+    if (!p->ev_valid) return fail(GLV_ERR_STATE, "no timed glv_griffinlim call yet (option 'timing')");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_out, p->ev0, p->ev1));
+    return GLV_OK;
+}
+
+extern "C" int glv_plan_set_inverse_basis(glv_plan* p, const float* pinv_host) {
+    if (!p || !pinv_host) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipMemcpy(p->d_pinv, pinv_host, sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
+    p->have_pinv = true;
+    return GLV_OK;
+}
+
+extern "C" int glv_mel_invert(glv_plan* p, const float* mel_db_dev, int batch, int frames_stride,
+                              float mean, float std_, float* S_dev, void* stream) {
+    if (!p || !mel_db_dev || !S_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (!p->have_pinv) return fail(GLV_ERR_STATE, "glv_plan_set_inverse_basis has not been called");
+    if (batch < 1 || frames_stride < 1) return fail(GLV_ERR_INVALID, "batch and frames_stride must be >= 1");
+    DeviceGuard guard(p->device);
+    const int64_t rows = (int64_t)batch * frames_stride;
+    const dim3 grid((p->F + 63) / 64, (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(mel_invert_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel_db_dev, p->d_pinv,
+                       rows, p->n_mels, p->F, mean, std_, S_dev);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+namespace {
+
+// enqueues the n_iter iteration kernels (and nothing else) on st
+int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool with_sc, hipStream_t st) {
+    IterArgs a = iter_args(p, frames_stride);
+    a.cmom = cmom;
+    int cur = 0;  // the iSTFT of the initial angles wrote buffer 0
+    for (int k = 0; k < n_iter; ++k) {
+        a.has_prev = k > 0;
+        a.sc_partial = with_sc ? p->d_sc_partial + (size_t)k * p->n_runs * 2 : nullptr;
+        set_io(p, a, cur, cur ^ 1);
+        HIP_TRY(p->launch_engine(MODE_ITER, with_sc, a, engine_grid(p), st));
+        cur ^= 1;
+    }
+    return GLV_OK;
+}
+
+}  // namespace
+
+extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phase0_dev, uint64_t seed,
+                              const int* n_frames_host, int batch, int frames_stride, int n_iter,
+                              float momentum, float* y_dev, int64_t y_stride, float* sc_curve_dev,
+                              void* stream) {
+    if (!p || !S_dev || !y_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (n_iter < 0) return fail(GLV_ERR_INVALID, "n_iter must be >= 0");
+    if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    if (rc != GLV_OK) return rc;
+    int max_t = 0;
+    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
+    if (y_stride < (int64_t)p->hop * (max_t - 1))
+        return fail(GLV_ERR_INVALID, "y_stride %lld shorter than hop*(n_frames-1) = %lld",
+                    (long long)y_stride, (long long)p->hop * (max_t - 1));
+    const bool with_sc = sc_curve_dev != nullptr && n_iter > 0;
+    if (with_sc) {
+        const size_t need = (size_t)n_iter * p->n_runs * 2;
+        if (need > p->sc_partial_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (p->d_sc_partial) (void)hipFree(p->d_sc_partial);
+            p->d_sc_partial = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_sc_partial), need * sizeof(float)));
+            p->sc_partial_cap = need;
+            if (p->graph_exec) {
+                (void)hipGraphExecDestroy(p->graph_exec);
+                p->graph_exec = nullptr;
+            }
+        }
+    }
+    const ElemArgs ea = elem_args(p, batch, frames_stride);
+    const float inv_n = 1.0f / (float)p->n_fft;
+    p->launch_init(ea, S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec, st);
+    HIP_TRY(hipGetLastError());
+
+    // inverse = istft(angles) of the initial phase
+    IterArgs a = iter_args(p, frames_stride);
+    set_io(p, a, 1, 0);
+    HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
+
+    const float cmom = momentum / (1.0f + momentum);
+    if (p->timing) HIP_TRY(hipEventRecord(p->ev0, st));
+    if (n_iter > 0) {
+        if (p->use_graph) {
+            const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch, cmom};
+            if (!p->graph_exec || !(key == p->graph_key)) {
+                if (p->graph_exec) {
+                    (void)hipGraphExecDestroy(p->graph_exec);
+                    p->graph_exec = nullptr;
+                }
+                hipStream_t cap = nullptr;
+                HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+                hipGraph_t graph = nullptr;
+                hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+                int lrc = GLV_OK;
+                if (e == hipSuccess) {
+                    lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap);
+                    e = hipStreamEndCapture(cap, &graph);
+                }
+                if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipStreamDestroy(cap);
+                if (lrc != GLV_OK) return lrc;
+                if (e != hipSuccess) {
+                    p->graph_exec = nullptr;
+                    return fail(GLV_ERR_HIP, "capturing the iteration loop failed: %s", hipGetErrorString(e));
+                }
+                p->graph_key = key;
+            }
+            HIP_TRY(hipGraphLaunch(p->graph_exec, st));
+        } else {
+            rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st);
+            if (rc != GLV_OK) return rc;
+        }
+    }
+    if (p->timing) {
+        HIP_TRY(hipEventRecord(p->ev1, st));
+        p->ev_valid = true;
+    }
+    const int last = n_iter & 1;
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
+                       p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, y_dev,
+                       y_stride);
+    HIP_TRY(hipGetLastError());
+    if (with_sc) {
+        hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
+                           p->d_sc_partial, p->n_runs, p->d_run_off, p->d_run_cnt, batch, n_iter,
+                           sc_curve_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return GLV_OK;
+}
+
+extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_samples_host, int batch,
+                                  int64_t y_stride, float eps, void* stream) {
+    if (!p || !y_dev || !n_samples_host) return fail(GLV_ERR_INVALID, "null argument");
+    if (batch < 1 || batch > p->max_batch)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t max_len = 1;
+    for (int b = 0; b < batch; ++b) {
+        if (n_samples_host[b] < 0 || n_samples_host[b] > y_stride)
+            return fail(GLV_ERR_INVALID, "n_samples[%d] = %d outside [0, y_stride]", b, n_samples_host[b]);
+        max_len = std::max<int64_t>(max_len, n_samples_host[b]);
+    }
+    // pageable source: the copy is staged before the call returns
+    HIP_TRY(hipMemcpyAsync(p->d_nsamples, n_samples_host, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(p->d_peak, 0, sizeof(unsigned) * batch, st));
+    const dim3 grid(std::min<unsigned>(grid_for(max_len, 256), 256), batch);
+    hipLaunchKernelGGL(peak_reduce_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak);
+    hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak, eps);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+                        int batch, int frames_stride, float* D_dev, void* stream) {
+    if (!p || !y_dev || !D_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    if (rc != GLV_OK) return rc;
+    int max_t = 0;
+    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
+    const int64_t max_len = (int64_t)p->hop * (max_t - 1);
+    if (y_stride < max_len) return fail(GLV_ERR_INVALID, "y_stride shorter than hop*(n_frames-1)");
+    const ElemArgs ea = elem_args(p, batch, frames_stride);
+    hipLaunchKernelGGL(pad_signal_kernel, dim3(grid_for(std::max<int64_t>(max_len, 1), 256), batch),
+                       dim3(256), 0, st, ea, y_dev, y_stride, p->d_ym[0]);
+    IterArgs a = iter_args(p, frames_stride);
+    a.raw_in = 1;
+    set_io(p, a, 0, 1);
+    HIP_TRY(p->launch_engine(MODE_STFT, false, a, engine_grid(p), st));
+    p->launch_convert(false, ea, p->d_spec, 1.0f, reinterpret_cast<cf*>(D_dev), st);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_host, int batch,
+                         int frames_stride, float* y_dev, int64_t y_stride, void* stream) {
+    if (!p || !y_dev || !D_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    if (rc != GLV_OK) return rc;
+    int max_t = 0;
+    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
+    if (y_stride < (int64_t)p->hop * (max_t - 1))
+        return fail(GLV_ERR_INVALID, "y_stride shorter than hop*(n_frames-1)");
+    const ElemArgs ea = elem_args(p, batch, frames_stride);
+    p->launch_convert(true, ea, reinterpret_cast<const cf*>(D_dev), 1.0f / (float)p->n_fft, p->d_spec, st);
+    IterArgs a = iter_args(p, frames_stride);
+    set_io(p, a, 1, 0);
+    HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
+                       p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, y_dev, y_stride);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}

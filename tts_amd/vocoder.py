@@ -1,0 +1,326 @@
+"""Mel -> waveform Griffin-Lim vocoder on MI355X.
+
+Drop-in for the reference function
+
+    mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length=256,
+                             win_length=2048, n_mels=80, fmax=8000)
+
+(reference vocoder/mel_audio.py:112-132; copies at vocoder/pra.py:65-80 and
+test.py:143-158) with the same positional signature, plus keyword-only extras
+whose defaults reproduce the reference behaviour, and a batched entry point.
+All arithmetic runs in libglvoc.so (hand-written HIP kernels); torch only owns
+device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from .filters import inverse_mel_basis
+
+__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch"]
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _int_array(values):
+    arr = np.ascontiguousarray(values, dtype=np.int32)
+    return arr, arr.ctypes.data_as(_lib.c_int_p)
+
+
+class GriffinLimPlan:
+    """Owns one ``glv_plan``: tables and device workspace for a fixed
+    (n_fft, hop_length, win_length, n_mels) and capacity (max_frames, max_batch).
+
+    Tensors passed in must be float32, contiguous and on the plan's device; the
+    methods enqueue work on torch's current stream for that device and return
+    without synchronising.
+    """
+
+    def __init__(self, n_fft=2048, hop_length=256, win_length=None, n_mels=80, max_frames=865,
+                 max_batch=1, device=None):
+        self._handle = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("tts_amd needs a ROCm GPU: torch.cuda.is_available() is False "
+                               "(there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_fft = int(n_fft)
+        self.hop_length = int(hop_length)
+        self.win_length = int(win_length) if win_length is not None else self.n_fft
+        self.n_mels = int(n_mels)
+        self.max_frames = int(max_frames)
+        self.max_batch = int(max_batch)
+        self.n_bins = self.n_fft // 2 + 1
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.glv_plan_create(ctypes.byref(handle), self.n_fft, self.hop_length,
+                                            self.win_length, self.n_mels, self.max_frames,
+                                            self.max_batch, self.device.index))
+        self._handle = handle
+        self._basis_key = None
+
+    def close(self):
+        if self._handle is not None:
+            self.lib.glv_plan_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------
+    def set_option(self, name, value):
+        _lib.check(self.lib.glv_plan_set_option(self._handle, name.encode(), int(value)))
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.glv_plan_workspace_bytes(self._handle))
+
+    def last_loop_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(self.lib.glv_plan_last_loop_ms(self._handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def set_inverse_basis(self, pinv):
+        pinv = np.ascontiguousarray(pinv, dtype=np.float32)
+        if pinv.shape != (self.n_bins, self.n_mels):
+            raise ValueError(f"inverse basis must be ({self.n_bins}, {self.n_mels}), got {pinv.shape}")
+        _lib.check(self.lib.glv_plan_set_inverse_basis(self._handle, pinv.ctypes.data_as(_lib.c_float_p)))
+
+    def set_mel_basis(self, sr, fmin=0.0, fmax=None):
+        key = (int(sr), float(fmin), None if fmax is None else float(fmax))
+        if key != self._basis_key:
+            self.set_inverse_basis(inverse_mel_basis(int(sr), self.n_fft, self.n_mels, float(fmin),
+                                                     None if fmax is None else float(fmax)))
+            self._basis_key = key
+
+    # -- helpers ---------------------------------------------------------------
+    def _check(self, t, shape_tail, name):
+        if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.is_contiguous()
+                and t.device == self.device):
+            raise ValueError(f"{name} must be a contiguous float32 tensor on {self.device}")
+        if tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+            raise ValueError(f"{name} must end in shape {tuple(shape_tail)}, got {tuple(t.shape)}")
+
+    def _frames(self, n_frames, batch, frames_stride):
+        if n_frames is None:
+            n_frames = [frames_stride] * batch
+        arr, ptr = _int_array(n_frames)
+        if arr.shape != (batch,):
+            raise ValueError(f"n_frames must have {batch} entries")
+        return arr, ptr
+
+    # -- stages ------------------------------------------------------------------
+    def mel_invert(self, mel_db, mean, std):
+        """(B, T, n_mels) normalised dB -> (B, T, F) linear "magnitudes"
+        (reference vocoder/mel_audio.py:114-123)."""
+        self._check(mel_db, (self.n_mels,), "mel_db")
+        if mel_db.dim() != 3:
+            raise ValueError("mel_db must be (B, T, n_mels)")
+        b, t, _ = mel_db.shape
+        out = torch.empty((b, t, self.n_bins), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_mel_invert(self._handle, _ptr(mel_db), b, t, float(mean), float(std),
+                                           _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def griffinlim(self, S, n_frames=None, phase0=None, seed=0, n_iter=60, momentum=0.99,
+                   return_sc=False, out=None):
+        """librosa.griffinlim on a (B, T, F) batch (reference vocoder/mel_audio.py:126).
+
+        ``phase0``: (B, T, F, 2) unit phasors, or None to draw them on the device
+        from ``seed``.  Returns y (B, hop*(T-1)), rows zero-filled past
+        hop*(n_frames[b]-1); with ``return_sc`` also the (B, n_iter) spectral
+        convergence curve.
+        """
+        self._check(S, (self.n_bins,), "S")
+        if S.dim() != 3:
+            raise ValueError("S must be (B, T, F)")
+        b, t, _ = S.shape
+        if phase0 is not None:
+            self._check(phase0, (t, self.n_bins, 2), "phase0")
+        nf, nf_ptr = self._frames(n_frames, b, t)
+        y_stride = self.hop_length * (t - 1)
+        if out is None:
+            out = torch.empty((b, y_stride), dtype=torch.float32, device=self.device)
+        else:
+            self._check(out, (y_stride,), "out")
+        sc = torch.empty((b, n_iter), dtype=torch.float32, device=self.device) \
+            if (return_sc and n_iter > 0) else None
+        _lib.check(self.lib.glv_griffinlim(self._handle, _ptr(S), _ptr(phase0), int(seed) & (2**64 - 1),
+                                           nf_ptr, b, t, int(n_iter), float(momentum), _ptr(out),
+                                           y_stride, _ptr(sc), _stream_ptr(self.device)))
+        return (out, sc) if return_sc else out
+
+    def peak_normalize(self, y, n_samples=None, eps=1e-6):
+        """In place audio / (max|audio| + eps) per row (reference vocoder/mel_audio.py:129)."""
+        self._check(y, (y.shape[-1],), "y")
+        b, stride = y.shape
+        if n_samples is None:
+            n_samples = [stride] * b
+        _, ptr = _int_array(n_samples)
+        _lib.check(self.lib.glv_peak_normalize(self._handle, _ptr(y), ptr, b, stride, float(eps),
+                                               _stream_ptr(self.device)))
+        return y
+
+    def stft(self, y, n_frames=None):
+        """(B, hop*(T-1)) -> (B, T, F, 2); librosa.stft(center=True, pad_mode='constant')."""
+        self._check(y, (y.shape[-1],), "y")
+        b, stride = y.shape
+        t = stride // self.hop_length + 1
+        nf, nf_ptr = self._frames(n_frames, b, t)
+        out = torch.zeros((b, t, self.n_bins, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_stft(self._handle, _ptr(y), stride, nf_ptr, b, t, _ptr(out),
+                                     _stream_ptr(self.device)))
+        return out
+
+    def istft(self, D, n_frames=None):
+        """(B, T, F, 2) -> (B, hop*(T-1)); librosa.istft(center=True)."""
+        self._check(D, (self.n_bins, 2), "D")
+        b, t = D.shape[0], D.shape[1]
+        nf, nf_ptr = self._frames(n_frames, b, t)
+        stride = self.hop_length * (t - 1)
+        out = torch.empty((b, stride), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_istft(self._handle, _ptr(D), nf_ptr, b, t, _ptr(out), stride,
+                                      _stream_ptr(self.device)))
+        return out
+
+
+# ---------------------------------------------------------------------------
+# plan cache for the functional API
+# ---------------------------------------------------------------------------
+_plans = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(n_fft, hop_length, win_length, n_mels, frames, batch, device=None):
+    """Returns a cached plan able to hold `batch` utterances of `frames` frames,
+    growing (re-creating) it when a larger request arrives."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (int(n_fft), int(hop_length), int(win_length), int(n_mels), dev.index)
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None or plan.max_frames < frames or plan.max_batch < batch:
+            max_frames = max(frames, plan.max_frames if plan else 0)
+            max_batch = max(batch, plan.max_batch if plan else 0)
+            if plan is not None:
+                plan.close()
+            plan = GriffinLimPlan(n_fft, hop_length, win_length, n_mels, max_frames, max_batch, dev)
+            _plans[key] = plan
+        return plan
+
+
+def _phase_tensor(init_phase, n_bins, frames, device):
+    """(F, T) phasors / angles / int seed -> (1, T, F, 2) float32 device tensor."""
+    if isinstance(init_phase, (int, np.integer)):
+        # librosa: rng = np.random.default_rng(seed); angles = phasor(2*pi*rng.random(S.shape))
+        rng = np.random.default_rng(int(init_phase))
+        init_phase = 2 * np.pi * rng.random(size=(n_bins, frames))
+    arr = np.asarray(init_phase)
+    if arr.shape != (n_bins, frames):
+        raise ValueError(f"init_phase must have shape ({n_bins}, {frames}), got {arr.shape}")
+    if not np.iscomplexobj(arr):
+        arr = np.cos(arr) + 1j * np.sin(arr)
+    arr = arr.astype(np.complex64)
+    pair = np.ascontiguousarray(np.stack([arr.real.T, arr.imag.T], axis=-1)[None], dtype=np.float32)
+    return torch.from_numpy(pair).to(device)
+
+
+def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length=256, win_length=2048,
+                             n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, init_phase=None,
+                             device=None, return_tensor=False, verbose=False):
+    """Normalised-dB mel (T, n_mels) -> peak-normalised waveform of hop_length*(T-1)
+    samples, as reference vocoder/mel_audio.py:112-132 computes it:
+    denormalise, dB->power, pinv(mel basis) @ mel, librosa.griffinlim(n_iter=60,
+    momentum=0.99, random initial phase), divide by (max|y| + 1e-6).
+
+    Keyword-only extras (defaults = reference behaviour):
+      n_iter, momentum   Griffin-Lim parameters the reference leaves at 60 / 0.99.
+      init_phase         None: fresh random phase per call (unseeded, like the
+                         reference); int: ``np.random.default_rng(seed)`` phase;
+                         (F, T) array of phasors or radians: that phase.
+      device             torch device (default: current ROCm device).
+      return_tensor      return the device tensor instead of a numpy array.
+      verbose            print what the reference prints (:130-131).
+    """
+    mel = mel_db.detach() if isinstance(mel_db, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(mel_db, dtype=np.float32))
+    if mel.dim() != 2 or mel.shape[1] != n_mels:
+        raise ValueError(f"mel_db must be (T, {n_mels}), got {tuple(mel.shape)}")
+    if momentum < 0:
+        raise ValueError(f"griffinlim() called with momentum={momentum} < 0")
+    frames = mel.shape[0]
+    plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
+    plan.set_mel_basis(sr, 0.0, fmax)
+    mel = mel.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
+    S = plan.mel_invert(mel, float(mean), float(std))
+    if init_phase is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+        phase0 = None
+    else:
+        seed = 0
+        phase0 = _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
+    y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)
+    plan.peak_normalize(y)
+    audio = y[0]
+    if verbose:
+        host = audio.cpu().numpy()
+        print(str(host))
+        print(len(host) / 22050)  # librosa.get_duration(y=audio) assumes sr=22050
+    if return_tensor:
+        return audio
+    return audio.cpu().numpy()
+
+
+def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop_length=256,
+                      win_length=2048, n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, phase0=None,
+                      seed=0, device=None, return_sc=False, normalize=True):
+    """Batched mel_to_audio_griffin_lim.
+
+    ``mel_db``: (B, T, n_mels) array/tensor (rows past lengths[b] ignored) or a
+    list of (T_b, n_mels) arrays.  Returns (audio, n_samples[, sc]) with audio a
+    (B, hop*(T_max-1)) device tensor whose row b holds n_samples[b] =
+    hop*(lengths[b]-1) samples followed by zeros.
+    """
+    if isinstance(mel_db, (list, tuple)):
+        lengths = [int(m.shape[0]) for m in mel_db]
+        t_max = max(lengths)
+        packed = np.zeros((len(mel_db), t_max, n_mels), dtype=np.float32)
+        for i, m in enumerate(mel_db):
+            packed[i, : lengths[i]] = m.cpu().numpy() if isinstance(m, torch.Tensor) else m
+        mel = torch.from_numpy(packed)
+    else:
+        mel = mel_db if isinstance(mel_db, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(mel_db, dtype=np.float32))
+    if mel.dim() != 3 or mel.shape[2] != n_mels:
+        raise ValueError(f"mel_db must be (B, T, {n_mels})")
+    b, t_max, _ = mel.shape
+    if lengths is None:
+        lengths = [t_max] * b
+    plan = get_plan(n_fft, hop_length, win_length, n_mels, t_max, b, device)
+    plan.set_mel_basis(sr, 0.0, fmax)
+    mel = mel.to(device=plan.device, dtype=torch.float32).contiguous()
+    S = plan.mel_invert(mel, float(mean), float(std))
+    res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
+                          return_sc=return_sc)
+    y, sc = res if return_sc else (res, None)
+    n_samples = [hop_length * (int(n) - 1) for n in lengths]
+    if normalize:
+        plan.peak_normalize(y, n_samples)
+    return (y, n_samples, sc) if return_sc else (y, n_samples)
