@@ -1,0 +1,33 @@
+#!/bin/bash
+# One rocprofv3 --pmc pass per argument (a quoted, space-separated counter group) over a
+# short bench run; prints the per-launch average of every counter for the iteration kernel.
+#   scripts/pmc_gpu.sh <tag> "<group 1>" ["<group 2>" ...]     (BENCH_ARGS env adds bench flags)
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "$@"; do
+  i=$((i+1))
+  timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; exit 1; }
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            k = row["Kernel_Name"]
+            if "gl_engine_kernel" not in k: continue
+            k = k[k.index("gl_engine_kernel"):][:40]
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+res = {k: {c: sum(v)/len(v) for c, v in d.items()} for k, d in acc.items()}
+for k, d in res.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:32s} {v:16.1f}")
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+PY

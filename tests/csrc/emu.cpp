@@ -29,7 +29,12 @@ void emu_launch(const IterArgs& a) {
         const RunDesc run = a.runs[ri];
         for (int l = 0; l < 64; ++l) e[l].init(a, a.tables, l, run);
         if (MODE != MODE_ISTFT)
-            for (int l = 0; l < 64; ++l) e[l].preload(a);
+            for (int l = 0; l < 64; ++l) {
+                e[l].preload(a);
+                e[l].prefetch_block(a, run.t_begin);
+            }
+        if (MODE == MODE_ITER)
+            for (int l = 0; l < 64; ++l) e[l].prefetch_spec(a, run.t_begin);
         for (int t = run.t_begin; t < run.t_end; ++t) {
             if (MODE != MODE_ISTFT) {
                 for (int l = 0; l < 64; ++l) e[l].ph0(a, t, b0.data());
@@ -109,6 +114,8 @@ struct Emu {
         a.y_utt_stride = (int64_t)blocks * H;
         a.w2 = tab.w2.data();
         a.iwss = tab.iwss.data();
+        a.iwss_head = tab.iwss_head.data();
+        a.iwss_tail = tab.iwss_tail.data();
         a.tables = tab.fft.data();
         a.inv_n = 1.0f / s.n_fft;
     }
@@ -122,7 +129,8 @@ struct Emu {
         for (int b = 0; b < batch; ++b)
             for (int64_t n = 0; n < y_stride; ++n)
                 finalize_sample(L, ym[buf].data(), yt[buf].data(), flags.data(), blocks, tab.w2.data(),
-                                tab.iwss.data(), y, y_stride, b, n);
+                                tab.iwss.data(), tab.iwss_head.data(), tab.iwss_tail.data(), y, y_stride,
+                                b, n);
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,

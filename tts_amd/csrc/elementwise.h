@@ -77,7 +77,8 @@ GLV_HD void spec_to_natural_element(const LayoutArgs& L, const cf* spec, cf* D_n
 // out[b][n] for n < y_stride; returns |value| for the peak search.
 GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const float* y_tail,
                              const unsigned char* tail_flag, int blocks_stride, const float* w2,
-                             const float* iwss, float* out, int64_t out_stride, int b, int64_t n) {
+                             const float* iwss, const float* iwss_head, const float* iwss_tail,
+                             float* out, int64_t out_stride, int b, int64_t n) {
     const int T = L.n_frames[b];
     const int64_t len = (int64_t)L.hop * (T - 1);
     float val = 0.f;
@@ -87,17 +88,9 @@ GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const flo
         const int64_t at = (int64_t)b * L.y_utt_stride + p;
         if (j < T) val = y_main[at];
         if (tail_flag[(int64_t)b * blocks_stride + j]) val += y_tail[at];
-        float iw;
-        if (j >= L.R - 1 && j <= T - 1) {
-            iw = iwss[s];
-        } else {
-            int t0 = j - L.R + 1;
-            if (t0 < 0) t0 = 0;
-            const int t1 = j < T - 1 ? j : T - 1;
-            float sum = 0.f;
-            for (int t = t0; t <= t1; ++t) sum += w2[(j - t) * L.hop + s];
-            iw = sum > 1.17549435e-38f ? 1.0f / sum : 1.0f;
-        }
+        const float iw = (j >= L.R - 1 && j <= T - 1)
+                             ? iwss[s]
+                             : edge_iwss_lookup(w2, iwss_head, iwss_tail, L.hop, L.R, T, j, s);
         val *= iw;
     }
     out[(int64_t)b * out_stride + n] = val;

@@ -53,6 +53,8 @@ struct IterArgs {
     int64_t y_utt_stride;     // floats
     const float* w2;          // squared window, N floats
     const float* iwss;        // reciprocal of the complete window-sum-square, H floats
+    const float* iwss_head;   // [R-1][H]: blocks 0..R-2 (frames before the first are missing)
+    const float* iwss_tail;   // [R-1][H]: blocks T..T+R-2 (frames after the last are missing)
     const cf* tables;         // twA | twB | twP | win
     float* sc_partial;        // [run][2] (numerator, denominator) or null
     float cmom;               // momentum / (1 + momentum)
@@ -70,6 +72,22 @@ GLV_HD float rcp_refined(float x) {
 #endif
 }
 
+// Reciprocal window-sum-square of sample s of block j when some of the R frames that
+// would cover it do not exist (utterance edges).  Head and tail cases come from host
+// tables; an utterance shorter than R frames can be truncated on both sides at once and
+// is summed here.
+GLV_HD float edge_iwss_lookup(const float* w2, const float* iwss_head, const float* iwss_tail, int H,
+                              int R, int T, int j, int s) {
+    if (j < R - 1 && j <= T - 1) return iwss_head[j * H + s];
+    if (j >= R - 1 && j > T - 1 && j - (T - 1) <= R - 1) return iwss_tail[(j - T) * H + s];
+    int t0 = j - R + 1;
+    if (t0 < 0) t0 = 0;
+    const int t1 = j < T - 1 ? j : T - 1;
+    float sum = 0.f;
+    for (int t = t0; t <= t1; ++t) sum += w2[(j - t) * H + s];
+    return sum > 1.17549435e-38f ? 1.0f / sum : 1.0f;
+}
+
 template <int A, int HB>
 struct Engine {
     using G = Geo<A>;
@@ -83,6 +101,10 @@ struct Engine {
     cf acc[E];
     cf v[E];
     cf iw[HB];
+    // loads issued one frame ahead of their use (software prefetch)
+    cf tp_n[E];
+    float s_n[E];
+    float s_nyq_n;
     int mbase[A];
     int lane;
     RunDesc run;
@@ -111,37 +133,40 @@ struct Engine {
 
     // reciprocal window-sum-square of sample s of block j near an utterance edge
     GLV_HD float edge_iwss(const IterArgs& a, int j, int s) const {
-        const int T = run.n_frames;
-        int t0 = j - R + 1;
-        if (t0 < 0) t0 = 0;
-        int t1 = j < T - 1 ? j : T - 1;
-        float sum = 0.f;
-        for (int t = t0; t <= t1; ++t) sum += a.w2[(j - t) * H + s];
-        return sum > kTiny ? 1.0f / sum : 1.0f;
+        return edge_iwss_lookup(a.w2, a.iwss_head, a.iwss_tail, H, R, run.n_frames, j, s);
     }
 
-    // block j of the previous iteration's signal: (main + tail) / wss, zero outside
-    // the signal proper (the zero padding of a centred STFT)
-    GLV_HD void load_block(const IterArgs& a, int j, cf* out) const {
-        const int T = run.n_frames;
-        if (j < R / 2 || j >= R / 2 + T - 1) {
+    // Block j of the previous iteration's signal is (main + tail) / wss, and zero outside
+    // the signal proper (the zero padding of a centred STFT).  Reading it is split in
+    // two so the loads can be issued a whole frame ahead of their use.
+    struct BlockFetch {
+        cf main[HB];
+        cf tail[HB];
+    };
+    GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1; }
+    GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
+        return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
+    }
+    GLV_HD void fetch_block(const IterArgs& a, int j, BlockFetch& f) const {
 #pragma unroll
-            for (int i = 0; i < HB; ++i) out[i] = cf{0.f, 0.f};
-            return;
-        }
+        for (int i = 0; i < HB; ++i) f.main[i] = f.tail[i] = cf{0.f, 0.f};
+        if (!block_valid(j)) return;
         const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H + 2 * lane;
-        const bool have_main = a.raw_in || j < T;
-        const bool tail = !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
-        const bool interior = j >= R - 1 && j <= T - 1;
+        if (a.raw_in || j < run.n_frames) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) f.main[i] = *reinterpret_cast<const cf*>(a.y_in + base + 128 * i);
+        }
+        if (block_has_tail(a, j)) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) f.tail[i] = *reinterpret_cast<const cf*>(a.y_in_tail + base + 128 * i);
+        }
+    }
+    GLV_HD void finish_block(const IterArgs& a, int j, const BlockFetch& f, cf* out) const {
+        const bool interior = j >= R - 1 && j <= run.n_frames - 1;
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
-            cf val = cf{0.f, 0.f};
-            if (have_main) val = *reinterpret_cast<const cf*>(a.y_in + base + 128 * i);
-            if (tail) {
-                const cf tl = *reinterpret_cast<const cf*>(a.y_in_tail + base + 128 * i);
-                val = val + tl;
-            }
-            if (!a.raw_in) {
+            cf val = f.main[i] + f.tail[i];
+            if (!a.raw_in && block_valid(j)) {
                 cf w = iw[i];
                 if (!interior) {
                     w.x = edge_iwss(a, j, 128 * i + 2 * lane);
@@ -152,6 +177,32 @@ struct Engine {
             }
             out[i] = val;
         }
+    }
+    GLV_HD void load_block(const IterArgs& a, int j, cf* out) const {
+        BlockFetch f;
+        fetch_block(a, j, f);
+        finish_block(a, j, f, out);
+    }
+    BlockFetch blk_n;
+
+    // issue the loads frame t will need: its newest signal block ...
+    GLV_HD void prefetch_block(const IterArgs& a, int t) {
+        if (t < run.t_end) fetch_block(a, t + R - 1, blk_n);
+    }
+    // ... and its previous spectrum and target magnitudes
+    GLV_HD void prefetch_spec(const IterArgs& a, int t) {
+        if (t >= run.t_end) return;
+        if (a.has_prev) load_spec(a, t, tp_n);
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const f4 sq = reinterpret_cast<const f4*>(sf)[q * 64 + lane];
+            s_n[4 * q] = sq.x;
+            s_n[4 * q + 1] = sq.y;
+            s_n[4 * q + 2] = sq.z;
+            s_n[4 * q + 3] = sq.w;
+        }
+        s_nyq_n = sf[P];
     }
 
     GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf* src) const {
@@ -170,7 +221,8 @@ struct Engine {
 
     // ---- phase 0: newest block, window, first DFT pass ----
     GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
-        load_block(a, t + R - 1, &raw[(R - 1) * HB]);
+        finish_block(a, t + R - 1, blk_n, &raw[(R - 1) * HB]);
+        prefetch_block(a, t + 1);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const cf wn = tab.win[r * 64 + lane];
@@ -220,25 +272,12 @@ struct Engine {
         cf m[E];
         F::mirror_load(m, r, mbase);
         F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
-        cf tp[E];
-        if (a.has_prev) load_spec(a, t, tp);
-        float s[E];
-        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
-#pragma unroll
-        for (int q = 0; q < E / 4; ++q) {
-            const f4 sq = reinterpret_cast<const f4*>(sf)[q * 64 + lane];
-            s[4 * q] = sq.x;
-            s[4 * q + 1] = sq.y;
-            s[4 * q + 2] = sq.z;
-            s[4 * q + 3] = sq.w;
-        }
-        const float s_nyq = sf[P];
         store_spec(a, t);
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) {
             const cf x = v[reg];
             const bool packed = (reg == 0) && (lane == 0);
-            const float sx = s[reg], sy = packed ? s_nyq : s[reg];
+            const float sx = s_n[reg], sy = packed ? s_nyq_n : s_n[reg];
             if (SC) {
                 const float mag = sqrtf(x.x * x.x + x.y * x.y);
                 const float ex = (packed ? fabsf(x.x) : mag) - fabsf(sx);
@@ -247,7 +286,7 @@ struct Engine {
                 sc_den += sx * sx + (packed ? sy * sy : 0.f);
             }
             cf d = x;
-            if (a.has_prev) d = cf{x.x - a.cmom * tp[reg].x, x.y - a.cmom * tp[reg].y};
+            if (a.has_prev) d = cf{x.x - a.cmom * tp_n[reg].x, x.y - a.cmom * tp_n[reg].y};
             const float mag = sqrtf(d.x * d.x + d.y * d.y);
             const float mx = packed ? fabsf(d.x) : mag;
             const float my = packed ? fabsf(d.y) : mag;
@@ -255,6 +294,7 @@ struct Engine {
             const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
             v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
         }
+        prefetch_spec(a, t + 1);
     }
     // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
     GLV_HD void ph3_load(const IterArgs& a, int t) { load_spec(a, t, v); }

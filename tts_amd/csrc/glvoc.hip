@@ -79,7 +79,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void gl_engine_kernel(IterArgs
 
     Eng e;
     e.init(a, tables, lane, a.runs[ri]);
-    if (MODE != MODE_ISTFT) e.preload(a);
+    if (MODE != MODE_ISTFT) {
+        e.preload(a);
+        e.prefetch_block(a, e.run.t_begin);
+    }
+    if (MODE == MODE_ITER) e.prefetch_spec(a, e.run.t_begin);
     for (int t = e.run.t_begin; t < e.run.t_end; ++t) {
         if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
@@ -176,25 +180,34 @@ __global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride,
 
 __global__ void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
                                 const unsigned char* tail_flag, int blocks_stride, const float* w2,
-                                const float* iwss, float* out, int64_t out_stride) {
+                                const float* iwss, const float* iwss_head, const float* iwss_tail,
+                                float* out, int64_t out_stride) {
     const int b = blockIdx.y;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
          n += (int64_t)gridDim.x * blockDim.x)
-        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, out, out_stride, b, n);
+        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head, iwss_tail, out,
+                        out_stride, b, n);
 }
 
-__global__ void peak_reduce_kernel(const float* y, int64_t y_stride, const int* n_samples,
-                                   unsigned* peak_bits) {
+__global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_t y_stride,
+                                                          const int* n_samples, unsigned* peak_bits) {
+    __shared__ float wave_max[4];
     const int b = blockIdx.y;
     const int64_t len = n_samples[b];
+    const float* row = y + (int64_t)b * y_stride;
     float m = 0.f;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
          n += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(y[(int64_t)b * y_stride + n]));
+        m = fmaxf(m, fabsf(row[n]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0) atomicMax(&peak_bits[b], __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per block; non-negative floats order like their bit patterns
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(&peak_bits[b], __float_as_uint(m));
+    }
 }
 
 __global__ void peak_scale_kernel(float* y, int64_t y_stride, const int* n_samples,
@@ -291,6 +304,8 @@ struct glv_plan {
     cf* d_tables = nullptr;
     float* d_w2 = nullptr;
     float* d_iwss = nullptr;
+    float* d_iwss_head = nullptr;
+    float* d_iwss_tail = nullptr;
     float* d_pinv = nullptr;
     bool have_pinv = false;
     // device workspace
@@ -403,7 +418,7 @@ void plan_free(glv_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
@@ -434,6 +449,8 @@ IterArgs iter_args(const glv_plan* p, int frames_stride) {
     a.y_utt_stride = (int64_t)p->blocks * p->hop;
     a.w2 = p->d_w2;
     a.iwss = p->d_iwss;
+    a.iwss_head = p->d_iwss_head;
+    a.iwss_tail = p->d_iwss_tail;
     a.tables = p->d_tables;
     a.inv_n = 1.0f / (float)p->n_fft;
     return a;
@@ -569,6 +586,8 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(dmalloc(p, &p->d_tables, tab.fft.size()));
     PLAN_TRY(dmalloc(p, &p->d_w2, tab.w2.size()));
     PLAN_TRY(dmalloc(p, &p->d_iwss, tab.iwss.size()));
+    PLAN_TRY(dmalloc(p, &p->d_iwss_head, tab.iwss_head.size()));
+    PLAN_TRY(dmalloc(p, &p->d_iwss_tail, tab.iwss_tail.size()));
     PLAN_TRY(dmalloc(p, &p->d_pinv, (size_t)p->F * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_spec, frames * p->P));
     PLAN_TRY(dmalloc(p, &p->d_S, frames * (p->P + 4)));
@@ -589,6 +608,10 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(hipMemcpy(p->d_tables, tab.fft.data(), tab.fft.size() * sizeof(cf), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(p->d_w2, tab.w2.data(), tab.w2.size() * sizeof(float), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(p->d_iwss, tab.iwss.data(), tab.iwss.size() * sizeof(float), hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(p->d_iwss_head, tab.iwss_head.data(), tab.iwss_head.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
+    PLAN_TRY(hipMemcpy(p->d_iwss_tail, tab.iwss_tail.data(), tab.iwss_tail.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipDeviceSynchronize());
@@ -753,8 +776,8 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
     }
     const int last = n_iter & 1;
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
-                       p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, y_dev,
-                       y_stride);
+                       p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
+                       p->d_iwss_tail, y_dev, y_stride);
     HIP_TRY(hipGetLastError());
     if (with_sc) {
         hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
@@ -781,7 +804,7 @@ extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_sample
     // pageable source: the copy is staged before the call returns
     HIP_TRY(hipMemcpyAsync(p->d_nsamples, n_samples_host, sizeof(int) * batch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(p->d_peak, 0, sizeof(unsigned) * batch, st));
-    const dim3 grid(std::min<unsigned>(grid_for(max_len, 256), 256), batch);
+    const dim3 grid(std::min<unsigned>(grid_for(max_len, 256 * 8), 64), batch);
     hipLaunchKernelGGL(peak_reduce_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak);
     hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak, eps);
     HIP_TRY(hipGetLastError());
@@ -828,7 +851,8 @@ extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_ho
     set_io(p, a, 1, 0);
     HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
-                       p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, y_dev, y_stride);
+                       p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail,
+                       y_dev, y_stride);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

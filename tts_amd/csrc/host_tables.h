@@ -17,6 +17,8 @@ struct HostTables {
     std::vector<cf> fft;      // twA | twB | twP | win   (Geo<A>::TABLES)
     std::vector<float> w2;    // squared window, N
     std::vector<float> iwss;  // reciprocal complete window-sum-square, H
+    std::vector<float> iwss_head;  // [R-1][H] blocks 0..R-2: only frames 0..j exist
+    std::vector<float> iwss_tail;  // [R-1][H] blocks T..T+R-2: frames past T-1 are missing
 };
 
 // Periodic Hann window of win_length, zero-padded centrally to n_fft
@@ -72,6 +74,22 @@ HostTables build_tables(int hop, int win_length) {
         for (int u = R - 1; u >= 0; --u) acc = (float)((double)acc + w[u * hop + s] * w[u * hop + s]);
         t.iwss[s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
     }
+    // utterance edges: block j < R-1 is covered by frames 0..j only (offsets j..0);
+    // block T-1+d, d = 1..R-1, by frames up to T-1 only (offsets R-1..d)
+    t.iwss_head.assign((size_t)std::max(1, R - 1) * hop, 1.0f);
+    t.iwss_tail.assign((size_t)std::max(1, R - 1) * hop, 1.0f);
+    for (int j = 0; j < R - 1; ++j)
+        for (int s = 0; s < hop; ++s) {
+            float acc = 0.f;
+            for (int u = j; u >= 0; --u) acc = (float)((double)acc + w[u * hop + s] * w[u * hop + s]);
+            t.iwss_head[(size_t)j * hop + s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
+        }
+    for (int d = 1; d <= R - 1; ++d)
+        for (int s = 0; s < hop; ++s) {
+            float acc = 0.f;
+            for (int u = R - 1; u >= d; --u) acc = (float)((double)acc + w[u * hop + s] * w[u * hop + s]);
+            t.iwss_tail[(size_t)(d - 1) * hop + s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
+        }
     return t;
 }
 
