@@ -81,6 +81,7 @@ def cpu_baseline(mel, mean, std, n_utts):
 
 
 def main():
+    global N_FFT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -88,11 +89,13 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--lengths", choices=["fixed", "ljspeech"], default="fixed")
+    ap.add_argument("--n-fft", type=int, default=N_FFT, help="n_fft = win_length (default workload: 1024)")
     ap.add_argument("--frames-per-run", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=32)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    N_FFT = args.n_fft
 
     import torch
     import torch.distributed as dist
@@ -169,7 +172,8 @@ def main():
         achieved = alg_bytes_iter / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.lengths == "fixed" and args.batch == BATCH and args.frames == FRAMES:
+        if (os.path.exists(tpath) and args.lengths == "fixed" and args.batch == BATCH
+                and args.frames == FRAMES and N_FFT == 1024):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("gl_engine_iter_bytes_per_launch")
         result = {
@@ -192,7 +196,7 @@ def main():
                        "global_batch": world * args.batch, "audio_seconds_per_step": round(world * audio_s, 3),
                        "realtime_factor": round(world * audio_s / (elapsed / args.steps), 1),
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "gl_engine_kernel<n_fft 1024, hop 256, iteration>",
+            "roofline": {"bound": "hbm", "kernel": f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "alg_bytes_per_launch": alg_bytes_iter,

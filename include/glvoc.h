@@ -119,7 +119,7 @@ int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int 
 
 /*
  * Tuning and measurement hooks (no counterpart in the reference).
- *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks),
+ *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
  *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
  *                        "timing" (0/1: bracket the iteration loop with hipEvents).
  *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration

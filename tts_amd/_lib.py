@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libglvoc.so")
+# GLVOC_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("GLVOC_LIB") or os.path.join(_HERE, "csrc", "libglvoc.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)

@@ -27,6 +27,17 @@
 
 #include "wave_fft.h"
 
+// Build-time tuning switches for the 16-values-per-lane engine (n_fft 2048), whose
+// register budget is tight: 1 = as for n_fft 1024 (slide the STFT input in registers,
+// fetch the previous spectrum a frame ahead).  Measured on MI355X at 64 x 865 frames:
+// both on with one wave per SIMD 370-389 us per iteration; either off, or two waves per
+// SIMD forced by the launch bound (scratch spills), 470-640 us.
+#ifndef GLV_SLIDE_ALL
+#define GLV_SLIDE_ALL 1
+#endif
+#ifndef GLV_PREFETCH_TP_ALL
+#define GLV_PREFETCH_TP_ALL 1
+#endif
 namespace glv {
 
 struct alignas(16) f4 {
@@ -96,8 +107,14 @@ struct Engine {
     static constexpr int H = 128 * HB;  // hop
     static constexpr int R = E / HB;    // frames covering one sample
     static constexpr float kTiny = 1.17549435e-38f;
+    // The STFT input of consecutive frames overlaps by N - H samples: the window slides in
+    // registers and only the newest block is loaded per frame (kSlide), or all R blocks
+    // are re-read every frame (L2 hits) to save E registers.
+    static constexpr bool kSlide = GLV_SLIDE_ALL || (A == 1);
+    // The previous spectrum is fetched a frame ahead (E more live registers) or on demand.
+    static constexpr bool kPrefetchTp = GLV_PREFETCH_TP_ALL || (A == 1);
 
-    cf raw[E];
+    cf raw[kSlide ? E : HB];
     cf acc[E];
     cf v[E];
     cf iw[HB];
@@ -192,7 +209,7 @@ struct Engine {
     // ... and its previous spectrum and target magnitudes
     GLV_HD void prefetch_spec(const IterArgs& a, int t) {
         if (t >= run.t_end) return;
-        if (a.has_prev) load_spec(a, t, tp_n);
+        if (kPrefetchTp && a.has_prev) load_spec(a, t, tp_n);
         const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
@@ -215,21 +232,41 @@ struct Engine {
 
     // blocks t_begin .. t_begin+R-2 of the first frame
     GLV_HD void preload(const IterArgs& a) {
+        if (!kSlide) return;
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) load_block(a, run.t_begin + q, &raw[q * HB]);
     }
 
     // ---- phase 0: newest block, window, first DFT pass ----
     GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
-        finish_block(a, t + R - 1, blk_n, &raw[(R - 1) * HB]);
-        prefetch_block(a, t + 1);
+        if (kSlide) {
+            finish_block(a, t + R - 1, blk_n, &raw[(R - 1) * HB]);
+            prefetch_block(a, t + 1);
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const cf wn = tab.win[r * 64 + lane];
-            v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
+            for (int r = 0; r < E; ++r) {
+                const cf wn = tab.win[r * 64 + lane];
+                v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
+            }
+#pragma unroll
+            for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
+        } else {
+            BlockFetch f[R - 1];
+#pragma unroll
+            for (int q = 0; q < R - 1; ++q) fetch_block(a, t + q, f[q]);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (q < R - 1)
+                    finish_block(a, t + q, f[q], &v[q * HB]);
+                else
+                    finish_block(a, t + R - 1, blk_n, &v[q * HB]);
+            }
+            prefetch_block(a, t + 1);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const cf wn = tab.win[r * 64 + lane];
+                v[r] = cf{v[r].x * wn.x, v[r].y * wn.y};
+            }
         }
-#pragma unroll
-        for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
         F::fwd_a(v, tab, w, lane);
     }
     GLV_HD void ph1_read(const cf* r) { F::fwd_b(v, tab, r, lane); }
@@ -271,6 +308,7 @@ struct Engine {
     GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
+        if (!kPrefetchTp && a.has_prev) load_spec(a, t, tp_n);
         F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
         store_spec(a, t);
 #pragma unroll

@@ -63,8 +63,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// second launch bound = waves per SIMD the register allocator must leave room for
+#ifndef GLV_MIN_WAVES_A1
+#define GLV_MIN_WAVES_A1 2
+#endif
+#ifndef GLV_MIN_WAVES_A2
+#define GLV_MIN_WAVES_A2 1
+#endif
 template <int A, int HB, int MODE, bool SC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void gl_engine_kernel(IterArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
+gl_engine_kernel(IterArgs a) {
     using G = Geo<A>;
     using Eng = Engine<A, HB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,7 +305,8 @@ struct glv_plan {
     int n_fft, hop, win_length, n_mels, max_frames, max_batch, device;
     int A, HB, R, P, F, blocks;  // blocks = padded H-sample blocks per utterance row
     // options
-    int frames_per_run = 12;
+    int frames_per_run = 0;  // 0 = choose from the batch and the device's wave slots
+    int wave_slots = 2048;   // runs the device holds at once (CUs x resident blocks x waves)
     int use_graph = 1;
     int timing = 0;
     // device tables
@@ -345,6 +354,7 @@ struct glv_plan {
     bool ev_valid = false;
     // kernel launchers for this shape
     hipError_t (*launch_engine)(int mode, bool sc, const IterArgs&, size_t grid, hipStream_t) = nullptr;
+    int (*engine_blocks_per_cu)() = nullptr;
     void (*launch_init)(const ElemArgs&, const float*, const cf*, uint64_t, float, float*, cf*,
                         hipStream_t) = nullptr;
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
@@ -368,6 +378,17 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_STFT, false>), g, b, lds, st, a);
     }
     return hipGetLastError();
+}
+
+template <int A, int HB>
+int engine_blocks_per_cu_t() {
+    using G = Geo<A>;
+    const size_t lds = (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER, false>,
+                                                     64 * kWavesPerBlock, lds) != hipSuccess)
+        n = 1;
+    return n < 1 ? 1 : n;
 }
 
 inline unsigned grid_for(int64_t total, int block) {
@@ -400,6 +421,7 @@ void launch_convert_t(bool to_native, const ElemArgs& ea, const cf* src, float i
 template <int A, int HB>
 void bind_launchers(glv_plan* p) {
     p->launch_engine = &launch_engine_t<A, HB>;
+    p->engine_blocks_per_cu = &engine_blocks_per_cu_t<A, HB>;
     p->launch_init = &launch_init_t<A>;
     p->launch_convert = &launch_convert_t<A>;
 }
@@ -481,7 +503,28 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     if (same) return GLV_OK;
     // the pinned staging buffers may still feed an earlier call's copies
     HIP_TRY(hipStreamSynchronize(st));
-    std::vector<RunDesc> runs = build_runs(n_frames_host, batch, p->frames_per_run, p->R);
+    std::vector<RunDesc> runs;
+    if (p->frames_per_run > 0) {
+        runs = build_runs(n_frames_host, batch, p->frames_per_run, p->R);
+    } else {
+        // One wave per run.  Pick the run length so that the runs fill the device's wave
+        // slots in a whole number of rounds: a handful of runs left over for an extra,
+        // nearly empty round would cost a full round of time.
+        int64_t total = 0;
+        int max_t = 0;
+        for (int b = 0; b < batch; ++b) {
+            total += n_frames_host[b];
+            max_t = std::max(max_t, n_frames_host[b]);
+        }
+        const int64_t slots = p->wave_slots;
+        const int64_t rounds = std::max<int64_t>(1, (total + slots * 20 - 1) / (slots * 20));
+        const int64_t cap = slots * rounds;
+        int fpr = (int)std::max<int64_t>(std::max(1, p->R - 1), (total + cap - 1) / cap);
+        for (;; ++fpr) {
+            runs = build_runs(n_frames_host, batch, fpr, p->R);
+            if ((int64_t)runs.size() <= cap || fpr >= max_t) break;
+        }
+    }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
     std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);
     memcpy(p->h_runs, runs.data(), runs.size() * sizeof(RunDesc));
@@ -580,6 +623,11 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
         }                                                                                     \
     } while (0)
 
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            p->wave_slots = prop.multiProcessorCount * p->engine_blocks_per_cu() * kWavesPerBlock;
+    }
     const size_t frames = (size_t)max_batch * max_frames;
     const size_t ylen = (size_t)max_batch * p->blocks * hop;
     p->max_runs = frames;
@@ -632,7 +680,7 @@ extern "C" int64_t glv_plan_workspace_bytes(const glv_plan* p) { return p ? p->w
 extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     if (!p || !name) return fail(GLV_ERR_INVALID, "null plan or option name");
     if (!strcmp(name, "frames_per_run")) {
-        if (value < 1) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 1");
+        if (value < 0) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 0 (0 = automatic)");
         p->frames_per_run = value;
     } else if (!strcmp(name, "use_graph")) {
         p->use_graph = value != 0;
