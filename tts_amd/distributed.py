@@ -1,0 +1,118 @@
+"""Multi-GPU use of the vocoder: one process per GPU, `torch.distributed` for the little
+communication there is.
+
+* Batch sharding: utterances are independent, so each rank synthesises its own subset and
+  nothing is exchanged until an optional final gather of the waveforms.
+* Time sharding of one long utterance: every rank owns a contiguous range of frames and,
+  once per Griffin-Lim iteration, swaps the (n_fft - hop) overlap-add samples at each shard
+  boundary with its two neighbours (point-to-point, no ring).
+
+The reference has no counterpart for either (it synthesises one utterance on one CPU
+thread, vocoder/mel_audio.py:138); the functions only orchestrate calls of the
+single-GPU entry points.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_by_length", "synthesize_sharded", "exchange_halos", "split_frames"]
+
+
+def shard_by_length(lengths, world_size):
+    """Deals utterance indices to ranks: longest first, each to the least loaded rank
+    (load = total frames).  Returns a list of index lists, one per rank, each in ascending
+    index order.  Deterministic, identical on every rank."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += int(lengths[i])
+    return [sorted(s) for s in shards]
+
+
+def _default_compute(mels, mean, std, **kw):
+    from .vocoder import griffin_lim_batch
+    return griffin_lim_batch(mels, mean, std, **kw)
+
+
+def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=None, **kw):
+    """Batch-sharded synthesis.  `mels` is the full list of (T_i, n_mels) arrays, present on
+    every rank.  Each rank synthesises `shard_by_length(...)[rank]` with `compute_fn`
+    (default: `griffin_lim_batch` on its GPU) - no communication - and, unless `gather_dst`
+    is None, the padded waveforms are gathered on rank `gather_dst`.
+
+    Returns on the gathering rank (or on every rank if it is not distributed) a list of
+    1-D numpy arrays in the order of `mels`; on other ranks, or with `gather_dst=None`, a
+    dict {global index: 1-D numpy array} of the local results.
+    """
+    compute_fn = compute_fn or _default_compute
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    lengths = [int(m.shape[0]) for m in mels]
+    mine = shard_by_length(lengths, world)[rank]
+    local = {}
+    if mine:
+        audio, n_samples = compute_fn([mels[i] for i in mine], mean, std, **kw)[:2]
+        audio = audio.detach().cpu().numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio)
+        for row, i, n in zip(audio, mine, n_samples):
+            local[i] = np.ascontiguousarray(row[:n])
+    if not distributed:
+        return [local[i] for i in range(len(mels))]
+    if gather_dst is None:
+        return local
+    # one gather of a (max rows, max samples) float32 block per rank; lengths travel as ints
+    shards = shard_by_length(lengths, world)
+    max_rows = max(len(s) for s in shards)
+    max_len = max((len(v) for v in local.values()), default=0)
+    dims = torch.tensor([max_len], dtype=torch.int64)
+    dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
+    max_len = int(dims.item())
+    block = torch.zeros((max_rows, max_len), dtype=torch.float32)
+    for r, i in enumerate(mine):
+        block[r, : len(local[i])] = torch.from_numpy(local[i])
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        block = block.cuda()
+    if rank == gather_dst:
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.gather(block, parts, dst=gather_dst, group=group)
+        out = [None] * len(mels)
+        for r, idxs in enumerate(shards):
+            rows = parts[r].cpu().numpy()
+            for k, i in enumerate(idxs):
+                out[i] = rows[k]
+        # trim every row to its own length: hop*(T-1) is known from the mel alone
+        hop = kw.get("hop_length", 256)
+        return [out[i][: hop * (lengths[i] - 1)] for i in range(len(mels))]
+    dist.gather(block, None, dst=gather_dst, group=group)
+    return local
+
+
+def split_frames(n_frames, world_size, min_frames=1):
+    """Contiguous, near-equal frame ranges [(t0, t1), ...] for time sharding."""
+    if n_frames < world_size * min_frames:
+        raise ValueError(f"{n_frames} frames cannot give {world_size} shards of >= {min_frames} frames")
+    return [(r * n_frames // world_size, (r + 1) * n_frames // world_size) for r in range(world_size)]
+
+
+def exchange_halos(to_prev, to_next, from_prev, from_next, *, group=None):
+    """One halo swap of a time-sharded iteration: send `to_prev` / `to_next` to ranks
+    rank-1 / rank+1 and receive `from_prev` / `from_next` from them (line topology: the
+    first rank has no previous, the last no next neighbour).  Tensors are the
+    (n_fft - hop)-sample overlap-add partial sums at the two shard boundaries."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, to_prev, rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, from_prev, rank - 1, group))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, to_next, rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, from_next, rank + 1, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
