@@ -104,6 +104,14 @@ int glv_griffinlim(glv_plan* plan, const float* S_dev, const float* phase0_dev, 
 int glv_peak_normalize(glv_plan* plan, float* y_dev, const int* n_samples_host, int batch,
                        int64_t y_stride, float eps, void* stream);
 
+/* The two halves of glv_peak_normalize, for callers that must combine the peak of
+ * several pieces first (time-sharded synthesis takes the maximum over ranks in between):
+ * peak_dev[b] = max|y[b, :n_samples[b]]|, then y[b] /= (peak_dev[b] + eps). */
+int glv_peak_reduce(glv_plan* plan, const float* y_dev, const int* n_samples_host, int batch,
+                    int64_t y_stride, float* peak_dev, void* stream);
+int glv_peak_scale(glv_plan* plan, float* y_dev, const int* n_samples_host, int batch,
+                   int64_t y_stride, const float* peak_dev, float eps, void* stream);
+
 /*
  * librosa.stft / librosa.istft with the plan's n_fft, hop and window, exposed
  * for stage-wise checks of the two transforms inside librosa.griffinlim
@@ -116,6 +124,39 @@ int glv_stft(glv_plan* plan, const float* y_dev, int64_t y_stride, const int* n_
              int batch, int frames_stride, float* D_dev, void* stream);
 int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int batch,
               int frames_stride, float* y_dev, int64_t y_stride, void* stream);
+
+/*
+ * Time-sharded librosa.griffinlim (reference vocoder/mel_audio.py:126) for one utterance
+ * too long for, or wanted faster than, one GPU: this device holds frames
+ * [frame_begin, frame_begin + frames_local) of frames_global.  The reference has no
+ * counterpart (it runs one utterance on one CPU thread); the arithmetic per frame is that of
+ * glv_griffinlim.  Per iteration each shard boundary needs one swap of
+ * glv_shard_halo_samples() = n_fft - hop floats in each direction, which the caller moves
+ * (RCCL point-to-point, or a device copy when both shards share a GPU):
+ *
+ *     glv_shard_begin(...);                 init + inverse STFT of the initial angles
+ *     swap();                               pack -> send/recv -> unpack
+ *     repeat n_iter times { glv_shard_step(); swap(); }
+ *     glv_shard_output_range(); glv_shard_end(y);
+ *
+ *   swap() = glv_shard_halo_pack(to_prev, to_next), exchange with ranks -1 / +1,
+ *            glv_shard_halo_unpack(from_prev, from_next).  The first shard has no previous
+ *            and the last no next neighbour; those pointers are ignored (may be NULL).
+ *   S_dev / phase0_dev hold only the local frames, (frames_local, F); a NULL phase is drawn
+ *   from `seed` per global frame index, so the result does not depend on the sharding.
+ *   glv_shard_end writes this shard's n_count samples, which start at sample n_begin of the
+ *   whole waveform (glv_shard_output_range), un-normalised.
+ * A shard needs at least 2*(n_fft/hop - 1) frames.  One shard per plan at a time.
+ */
+int glv_shard_begin(glv_plan* plan, const float* S_dev, const float* phase0_dev, uint64_t seed,
+                    int frame_begin, int frames_local, int frames_global, void* stream);
+int glv_shard_step(glv_plan* plan, float momentum, void* stream);
+int glv_shard_halo_samples(const glv_plan* plan);
+int glv_shard_halo_pack(glv_plan* plan, float* to_prev_dev, float* to_next_dev, void* stream);
+int glv_shard_halo_unpack(glv_plan* plan, const float* from_prev_dev, const float* from_next_dev,
+                          void* stream);
+int glv_shard_output_range(const glv_plan* plan, int64_t* n_begin, int64_t* n_count);
+int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 
 /*
  * Tuning and measurement hooks (no counterpart in the reference).

@@ -103,7 +103,7 @@ struct Emu {
             yt[i].assign((size_t)batch * blocks * H, 0.f);
         }
         sc_partial.assign(2 * runs.size(), 0.f);
-        L = LayoutArgs{s.n_fft, s.hop, F, P, R, Ts, (int64_t)blocks * H, nf.data()};
+        L = LayoutArgs{s.n_fft, s.hop, F, P, R, Ts, (int64_t)blocks * H, nf.data(), 0, 0};
         memset(&a, 0, sizeof(a));
         a.runs = runs.data();
         a.n_runs = (int)runs.size();

@@ -250,3 +250,55 @@ def test_error_behaviour(voc):
     plan.close()
     with pytest.raises(ValueError):
         voc.mel_to_audio_griffin_lim(np.zeros((10, 40), np.float32), 0.0, 1.0)
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,shards", [(1024, 256, 97, 3), (2048, 256, 120, 2), (1024, 256, 64, 4)])
+def test_time_sharded_equals_single_device(voc, O, lj001, n_fft, hop, frames, shards):
+    """One utterance split along time into shards that swap n_fft - hop samples per iteration
+    (here: several plans on one GPU, the swap is a device copy; across GPUs the same buffers
+    travel over RCCL).  Must agree with the unsharded run and the oracle."""
+    from tts_amd.distributed import split_frames
+    mel, mean, std = lj001
+    s = O.mel_invert(mel[:frames], mean, std, n_fft=n_fft)
+    ph = phasors(21, s.shape[0], frames)
+    n_iter = 6
+    ref = O.griffinlim(s, n_iter=n_iter, hop_length=hop, win_length=n_fft, init_phase=ph)
+    sd, pd = dev(to_btf(s)), dev(to_btf2(ph))
+    whole = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, 1)
+    y_whole = whole.griffinlim(sd, phase0=pd, n_iter=n_iter).cpu().numpy()[0]
+    whole.close()
+    ranges = split_frames(frames, shards, min_frames=2 * (n_fft // hop - 1))
+    plans = [voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t1 - t0, 1) for t0, t1 in ranges]
+    for p, (t0, t1) in zip(plans, ranges):
+        p.set_option("frames_per_run", 9)
+        p.shard_begin(sd[0, t0:t1].contiguous(), t0, frames, phase0=pd[0, t0:t1].contiguous())
+
+    def swap():
+        packed = [p.shard_halo_pack() for p in plans]
+        for r, p in enumerate(plans):
+            from_prev = packed[r - 1][1] if r > 0 else None
+            from_next = packed[r + 1][0] if r < len(plans) - 1 else None
+            p.shard_halo_unpack(from_prev if from_prev is not None else p.shard_halo_buffers()[0],
+                                from_next if from_next is not None else p.shard_halo_buffers()[1])
+
+    swap()
+    for _ in range(n_iter):
+        for p in plans:
+            p.shard_step(0.99)
+        swap()
+    pieces = [p.shard_end() for p in plans]
+    y = np.zeros(hop * (frames - 1), np.float32)
+    covered = np.zeros_like(y, dtype=bool)
+    for piece, n_begin in pieces:
+        arr = piece.cpu().numpy()
+        assert not covered[n_begin:n_begin + len(arr)].any()
+        y[n_begin:n_begin + len(arr)] = arr
+        covered[n_begin:n_begin + len(arr)] = True
+    assert covered.all()
+    assert rel_l2(y, y_whole) < 2e-5
+    assert rel_l2(y, ref) < 1e-4
+    # peak normalisation from per-shard maxima == global
+    peaks = [float(p.peak_reduce(piece.unsqueeze(0)).cpu()[0]) for p, (piece, _) in zip(plans, pieces)]
+    assert max(peaks) == float(np.max(np.abs(y)))
+    for p in plans:
+        p.close()

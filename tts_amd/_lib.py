@@ -33,6 +33,21 @@ SIGNATURES = {
                                       ctypes.c_void_p, ctypes.c_void_p]),
     "glv_peak_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
+    "glv_peak_reduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
+                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "glv_peak_scale": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "glv_shard_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "glv_shard_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "glv_shard_halo_samples": (ctypes.c_int, [ctypes.c_void_p]),
+    "glv_shard_halo_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p]),
+    "glv_shard_halo_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
+    "glv_shard_output_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                              ctypes.POINTER(ctypes.c_int64)]),
+    "glv_shard_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_stft": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_istft": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,

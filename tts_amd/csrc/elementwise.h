@@ -11,7 +11,9 @@ struct LayoutArgs {
     int n_fft, hop, F, P, R;
     int frames_stride;        // frames per utterance row in caller arrays and in spec/S
     int64_t y_utt_stride;     // floats per utterance in the padded overlap-add buffers
-    const int* n_frames;      // [batch]
+    const int* n_frames;      // [batch] frames of the whole utterance
+    int frames_local;         // > 0: only this many frames are held here (time shard)
+    int64_t frame_origin;     // global index of local frame 0 (time shard), else 0
 };
 
 // --- natural (B, T, F) arrays -> native state for the iteration -------------
@@ -30,7 +32,7 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
     snat[native_s_index(reg, lane)] = s;
     auto phase_at = [&](int kk) -> cf {
         if (phase_nat) return phase_nat[fr * L.F + kk];
-        const float u = counter_uniform(seed, (uint64_t)(fr * L.F + kk));
+        const float u = counter_uniform(seed, (uint64_t)((fr + L.frame_origin) * L.F + kk));
         const float ph = 6.28318530717958647692f * u;
         return cf{cosf(ph), sinf(ph)};
     };

@@ -155,7 +155,7 @@ __global__ void init_native_kernel(ElemArgs ea, const float* S_nat, const cf* ph
         const int q = (int)(i % P);
         const int64_t fr = i / P;
         const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-        if (t < ea.L.n_frames[b])
+        if (t < (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b]))
             init_native_element<A>(ea.L, S_nat, phase_nat, seed, inv_n, S_native, spec, b, t, q);
     }
 }
@@ -169,7 +169,7 @@ __global__ void spec_convert_kernel(ElemArgs ea, const cf* src, float inv_n, cf*
         const int q = (int)(i % P);
         const int64_t fr = i / P;
         const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-        if (t >= ea.L.n_frames[b]) continue;
+        if (t >= (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b])) continue;
         if (TO_NATIVE)
             spec_to_native_element<A>(ea.L, src, inv_n, dst, b, t, q);
         else
@@ -189,12 +189,14 @@ __global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride,
 __global__ void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
                                 const unsigned char* tail_flag, int blocks_stride, const float* w2,
                                 const float* iwss, const float* iwss_head, const float* iwss_tail,
-                                float* out, int64_t out_stride) {
+                                float* out, int64_t out_stride, int64_t n_begin) {
+    // samples [n_begin, n_begin + out_stride) of every row; pointers of a time shard are
+    // pre-shifted so that global sample / block indices address them
     const int b = blockIdx.y;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
          n += (int64_t)gridDim.x * blockDim.x)
         finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head, iwss_tail, out,
-                        out_stride, b, n);
+                        out_stride, b, n_begin + n);
 }
 
 __global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_t y_stride,
@@ -349,6 +351,9 @@ struct glv_plan {
                    frames_stride == o.frames_stride && batch == o.batch && cmom == o.cmom;
         }
     } graph_key{};
+    // time-shard state (glv_shard_*): frames [t0, t1) of a T-frame utterance live here
+    bool shard_active = false;
+    int shard_t0 = 0, shard_t1 = 0, shard_T = 0, shard_cur = 0, shard_k = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -454,7 +459,7 @@ void plan_free(glv_plan* p) {
 ElemArgs elem_args(const glv_plan* p, int batch, int frames_stride) {
     ElemArgs ea;
     ea.L = LayoutArgs{p->n_fft, p->hop, p->F, p->P, p->R, frames_stride,
-                      (int64_t)p->blocks * p->hop, p->d_nframes};
+                      (int64_t)p->blocks * p->hop, p->d_nframes, 0, 0};
     ea.batch = batch;
     return ea;
 }
@@ -825,7 +830,7 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
     const int last = n_iter & 1;
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
-                       p->d_iwss_tail, y_dev, y_stride);
+                       p->d_iwss_tail, y_dev, y_stride, (int64_t)0);
     HIP_TRY(hipGetLastError());
     if (with_sc) {
         hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
@@ -836,13 +841,191 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
     return GLV_OK;
 }
 
-extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_samples_host, int batch,
-                                  int64_t y_stride, float eps, void* stream) {
-    if (!p || !y_dev || !n_samples_host) return fail(GLV_ERR_INVALID, "null argument");
-    if (batch < 1 || batch > p->max_batch)
-        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+
+// ---------------------------------------------------------------------------
+// time sharding: one long utterance, frames [t0, t1) on this device
+// ---------------------------------------------------------------------------
+namespace {
+
+// Engine arguments in GLOBAL frame / block coordinates: base pointers are moved back by the
+// shard's origin so that frame t and block j of the whole utterance address local storage.
+IterArgs shard_iter_args(const glv_plan* p) {
+    IterArgs a = iter_args(p, p->max_frames);
+    const int64_t t0 = p->shard_t0;
+    a.spec = p->d_spec - t0 * p->P;
+    a.S = p->d_S - t0 * (p->P + 4);
+    return a;
+}
+
+void shard_set_io(const glv_plan* p, IterArgs& a, int in, int out) {
+    const int64_t off = (int64_t)p->shard_t0 * p->hop;
+    a.y_in = p->d_ym[in] - off;
+    a.y_in_tail = p->d_yt[in] - off;
+    a.y_out = p->d_ym[out] - off;
+    a.y_out_tail = p->d_yt[out] - off;
+}
+
+int shard_check(const glv_plan* p) {
+    if (!p) return fail(GLV_ERR_INVALID, "null plan");
+    if (!p->shard_active) return fail(GLV_ERR_STATE, "glv_shard_begin has not been called");
+    return GLV_OK;
+}
+
+}  // namespace
+
+extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* phase0_dev, uint64_t seed,
+                               int frame_begin, int frames_local, int frames_global, void* stream) {
+    if (!p || !S_dev) return fail(GLV_ERR_INVALID, "null argument");
+    const int t0 = frame_begin, t1 = frame_begin + frames_local, T = frames_global;
+    if (t0 < 0 || frames_local < 1 || t1 > T || T < 2)
+        return fail(GLV_ERR_INVALID, "shard [%d, %d) does not lie inside [0, %d)", t0, t1, T);
+    if (frames_local > p->max_frames)
+        return fail(GLV_ERR_INVALID, "frames_local %d exceeds the plan's max_frames %d", frames_local,
+                    p->max_frames);
+    if (frames_local < 2 * (p->R - 1) && frames_local < T)
+        return fail(GLV_ERR_INVALID, "a shard needs at least %d frames", 2 * (p->R - 1));
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));  // pinned staging buffers are rewritten below
+    int fpr = p->frames_per_run;
+    if (fpr <= 0) fpr = std::max(p->R - 1, (frames_local + p->wave_slots - 1) / p->wave_slots);
+    std::vector<RunDesc> runs = build_runs(&frames_local, 1, fpr, p->R);
+    for (RunDesc& r : runs) {
+        r.t_begin += t0;
+        r.t_end += t0;
+        r.n_frames = T;
+    }
+    // blocks completed by the tail buffer, indexed from the shard's first block
+    std::vector<unsigned char> flags((size_t)p->blocks, 0);
+    auto mark = [&](int j) {
+        if (j - t0 >= 0 && j - t0 < p->blocks) flags[j - t0] = 1;
+    };
+    for (const RunDesc& r : runs)
+        for (int q = 0; q < p->R - 1; ++q) mark(r.t_end + q);
+    if (t0 > 0)
+        for (int q = 0; q < p->R - 1; ++q) mark(t0 + q);  // tails of the previous shard's last run
+    memcpy(p->h_runs, runs.data(), runs.size() * sizeof(RunDesc));
+    memcpy(p->h_flags, flags.data(), flags.size());
+    p->h_ints[0] = T;
+    HIP_TRY(hipMemcpyAsync(p->d_runs, p->h_runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_flags, p->h_flags, flags.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_nframes, p->h_ints, sizeof(int), hipMemcpyHostToDevice, st));
+    p->cur_nframes.clear();  // the batch path must rebuild its own tables afterwards
+    p->n_runs = (int)runs.size();
+    p->shard_t0 = t0;
+    p->shard_t1 = t1;
+    p->shard_T = T;
+    p->shard_cur = 0;
+    p->shard_k = 0;
+    p->shard_active = true;
+    // halo regions nobody writes on the outermost shards must read as zero
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMemsetAsync(p->d_ym[i], 0, sizeof(float) * p->blocks * p->hop, st));
+        HIP_TRY(hipMemsetAsync(p->d_yt[i], 0, sizeof(float) * p->blocks * p->hop, st));
+    }
+    ElemArgs ea = elem_args(p, 1, p->max_frames);
+    ea.L.frames_local = frames_local;
+    ea.L.frame_origin = t0;
+    p->launch_init(ea, S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, 1.0f / (float)p->n_fft, p->d_S,
+                   p->d_spec, st);
+    HIP_TRY(hipGetLastError());
+    IterArgs a = shard_iter_args(p);
+    shard_set_io(p, a, 1, 0);
+    HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
+    DeviceGuard guard(p->device);
+    IterArgs a = shard_iter_args(p);
+    a.cmom = momentum / (1.0f + momentum);
+    a.has_prev = p->shard_k > 0;
+    shard_set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
+    HIP_TRY(p->launch_engine(MODE_ITER, false, a, engine_grid(p), (hipStream_t)stream));
+    p->shard_cur ^= 1;
+    p->shard_k++;
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_halo_samples(const glv_plan* p) { return p ? (p->R - 1) * p->hop : 0; }
+
+extern "C" int glv_shard_halo_pack(glv_plan* p, float* to_prev_dev, float* to_next_dev, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (p->R - 1) * p->hop;
+    const int cur = p->shard_cur;
+    // towards the previous shard: this shard's "head" partial sums of blocks [t0, t0+R-1)
+    if (to_prev_dev && p->shard_t0 > 0)
+        HIP_TRY(hipMemcpyAsync(to_prev_dev, p->d_ym[cur], bytes, hipMemcpyDeviceToDevice, st));
+    // towards the next shard: this shard's "tail" partial sums of blocks [t1, t1+R-1)
+    if (to_next_dev && p->shard_t1 < p->shard_T)
+        HIP_TRY(hipMemcpyAsync(to_next_dev, p->d_yt[cur] + (int64_t)(p->shard_t1 - p->shard_t0) * p->hop, bytes,
+                               hipMemcpyDeviceToDevice, st));
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_halo_unpack(glv_plan* p, const float* from_prev_dev, const float* from_next_dev,
+                                     void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (p->R - 1) * p->hop;
+    const int cur = p->shard_cur;
+    if (from_prev_dev && p->shard_t0 > 0)
+        HIP_TRY(hipMemcpyAsync(p->d_yt[cur], from_prev_dev, bytes, hipMemcpyDeviceToDevice, st));
+    if (from_next_dev && p->shard_t1 < p->shard_T)
+        HIP_TRY(hipMemcpyAsync(p->d_ym[cur] + (int64_t)(p->shard_t1 - p->shard_t0) * p->hop, from_next_dev, bytes,
+                               hipMemcpyDeviceToDevice, st));
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_output_range(const glv_plan* p, int64_t* n_begin, int64_t* n_count) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (!n_begin || !n_count) return fail(GLV_ERR_INVALID, "null argument");
+    // blocks [t0, t1) belong to this shard; the signal proper starts at block R/2, and the
+    // last shard also owns the blocks past the last frame
+    const int64_t half = p->R / 2;
+    const int64_t b0 = std::max<int64_t>(p->shard_t0, half) - half;
+    const int64_t b1 = (p->shard_t1 < p->shard_T) ? std::max<int64_t>(p->shard_t1, half) - half
+                                                  : (int64_t)p->shard_T - 1;
+    *n_begin = b0 * p->hop;
+    *n_count = std::max<int64_t>(0, b1 - b0) * p->hop;
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_end(glv_plan* p, float* y_dev, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (!y_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    int64_t n_begin = 0, n_count = 0;
+    glv_shard_output_range(p, &n_begin, &n_count);
+    if (n_count > 0) {
+        ElemArgs ea = elem_args(p, 1, p->max_frames);
+        const int64_t off = (int64_t)p->shard_t0 * p->hop;
+        const int cur = p->shard_cur;
+        hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(n_count, 256), 1), dim3(256), 0, (hipStream_t)stream,
+                           ea, p->d_ym[cur] - off, p->d_yt[cur] - off, p->d_flags - p->shard_t0, p->blocks,
+                           p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, y_dev - n_begin, n_count, n_begin);
+        HIP_TRY(hipGetLastError());
+    }
+    p->shard_active = false;
+    return GLV_OK;
+}
+
+namespace {
+
+int peak_prepare(glv_plan* p, const int* n_samples_host, int batch, int64_t y_stride, hipStream_t st,
+                 dim3* grid) {
+    if (batch < 1 || batch > p->max_batch)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
     int64_t max_len = 1;
     for (int b = 0; b < batch; ++b) {
         if (n_samples_host[b] < 0 || n_samples_host[b] > y_stride)
@@ -851,12 +1034,50 @@ extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_sample
     }
     // pageable source: the copy is staged before the call returns
     HIP_TRY(hipMemcpyAsync(p->d_nsamples, n_samples_host, sizeof(int) * batch, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(p->d_peak, 0, sizeof(unsigned) * batch, st));
-    const dim3 grid(std::min<unsigned>(grid_for(max_len, 256 * 8), 64), batch);
-    hipLaunchKernelGGL(peak_reduce_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak);
-    hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples, p->d_peak, eps);
+    *grid = dim3(std::min<unsigned>(grid_for(max_len, 256 * 8), 64), batch);
+    return GLV_OK;
+}
+
+}  // namespace
+
+extern "C" int glv_peak_reduce(glv_plan* p, const float* y_dev, const int* n_samples_host, int batch,
+                               int64_t y_stride, float* peak_dev, void* stream) {
+    if (!p || !y_dev || !n_samples_host || !peak_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid;
+    int rc = peak_prepare(p, n_samples_host, batch, y_stride, st, &grid);
+    if (rc != GLV_OK) return rc;
+    // max|y| >= 0, so the float's bit pattern orders like the value and 0 bits is the identity
+    HIP_TRY(hipMemsetAsync(peak_dev, 0, sizeof(float) * batch, st));
+    hipLaunchKernelGGL(peak_reduce_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples,
+                       reinterpret_cast<unsigned*>(peak_dev));
     HIP_TRY(hipGetLastError());
     return GLV_OK;
+}
+
+extern "C" int glv_peak_scale(glv_plan* p, float* y_dev, const int* n_samples_host, int batch,
+                              int64_t y_stride, const float* peak_dev, float eps, void* stream) {
+    if (!p || !y_dev || !n_samples_host || !peak_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid;
+    int rc = peak_prepare(p, n_samples_host, batch, y_stride, st, &grid);
+    if (rc != GLV_OK) return rc;
+    hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples,
+                       reinterpret_cast<const unsigned*>(peak_dev), eps);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_samples_host, int batch,
+                                  int64_t y_stride, float eps, void* stream) {
+    if (!p) return fail(GLV_ERR_INVALID, "null argument");
+    int rc = glv_peak_reduce(p, y_dev, n_samples_host, batch, y_stride, reinterpret_cast<float*>(p->d_peak),
+                             stream);
+    if (rc != GLV_OK) return rc;
+    return glv_peak_scale(p, y_dev, n_samples_host, batch, y_stride, reinterpret_cast<const float*>(p->d_peak),
+                          eps, stream);
 }
 
 extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
@@ -900,7 +1121,7 @@ extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_ho
     HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail,
-                       y_dev, y_stride);
+                       y_dev, y_stride, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

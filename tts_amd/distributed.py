@@ -17,7 +17,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_by_length", "synthesize_sharded", "exchange_halos", "split_frames"]
+__all__ = ["shard_by_length", "synthesize_sharded", "exchange_halos", "split_frames",
+           "griffin_lim_time_sharded"]
 
 
 def shard_by_length(lengths, world_size):
@@ -116,3 +117,55 @@ def exchange_halos(to_prev, to_next, from_prev, from_next, *, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+
+
+def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length=256, win_length=None,
+                             n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, seed=0, group=None,
+                             device=None, normalize=True):
+    """Long-form synthesis of ONE utterance sharded along time over the ranks of `group`
+    (BASELINE config 4: a 10-minute mel over 8 GPUs).
+
+    `mel_db` is the whole (T, n_mels) mel, present on every rank; rank r keeps frames
+    `split_frames(T, world)[r]`, inverts and iterates only those, and swaps n_fft - hop
+    samples with each neighbour once per iteration (61 swaps for 60 iterations).  The peak
+    for the final normalisation is one all-reduce(MAX) of one float.
+
+    Returns (y_local, n_begin): a float32 device tensor with this rank's samples
+    [n_begin, n_begin + len(y_local)) of the waveform.
+    """
+    from .vocoder import get_plan
+    win_length = n_fft if win_length is None else win_length
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mel = mel_db if isinstance(mel_db, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(mel_db, dtype=np.float32))
+    frames = mel.shape[0]
+    r_cover = n_fft // hop_length
+    t0, t1 = split_frames(frames, world, min_frames=2 * (r_cover - 1))[rank]
+    plan = get_plan(n_fft, hop_length, win_length, n_mels, max(t1 - t0, 2), 1, device)
+    plan.set_mel_basis(sr, 0.0, fmax)
+    local = mel[t0:t1].to(device=plan.device, dtype=torch.float32).contiguous()
+    s_local = plan.mel_invert(local.unsqueeze(0), float(mean), float(std))[0]
+    plan.shard_begin(s_local, t0, frames, seed=seed)
+
+    def swap():
+        to_prev, to_next = plan.shard_halo_pack()
+        from_prev, from_next = plan.shard_halo_buffers()
+        if dist.get_backend(group) != "nccl":
+            torch.cuda.current_stream(plan.device).synchronize()  # RCCL orders itself after the stream
+        exchange_halos(to_prev, to_next, from_prev, from_next, group=group)
+        plan.shard_halo_unpack(from_prev, from_next)
+
+    swap()
+    for _ in range(n_iter):
+        plan.shard_step(momentum)
+        swap()
+    y, n_begin = plan.shard_end()
+    if normalize and y.numel():
+        row = y.unsqueeze(0)
+        peak = plan.peak_reduce(row)
+        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)
+        plan.peak_scale(row, peak)
+    elif normalize:
+        peak = torch.zeros((1,), dtype=torch.float32, device=plan.device)
+        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)
+    return y, n_begin

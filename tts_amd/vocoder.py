@@ -177,6 +177,72 @@ class GriffinLimPlan:
                                                _stream_ptr(self.device)))
         return y
 
+    def peak_reduce(self, y, n_samples=None):
+        """max|y| per row as a (B,) float32 device tensor (first half of peak_normalize)."""
+        self._check(y, (y.shape[-1],), "y")
+        b, stride = y.shape
+        _, ptr = _int_array([stride] * b if n_samples is None else n_samples)
+        peak = torch.empty((b,), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_peak_reduce(self._handle, _ptr(y), ptr, b, stride, _ptr(peak),
+                                            _stream_ptr(self.device)))
+        return peak
+
+    def peak_scale(self, y, peak, n_samples=None, eps=1e-6):
+        """In place y[b] /= (peak[b] + eps) (second half of peak_normalize)."""
+        self._check(y, (y.shape[-1],), "y")
+        b, stride = y.shape
+        self._check(peak, (b,), "peak")
+        _, ptr = _int_array([stride] * b if n_samples is None else n_samples)
+        _lib.check(self.lib.glv_peak_scale(self._handle, _ptr(y), ptr, b, stride, _ptr(peak), float(eps),
+                                           _stream_ptr(self.device)))
+        return y
+
+    # -- time sharding: this plan holds frames [frame_begin, frame_begin + T_local) -----
+    def shard_begin(self, S_local, frame_begin, frames_global, phase0=None, seed=0):
+        """Starts a time-sharded Griffin-Lim on the local (T_local, F) slice of S; see
+        include/glvoc.h (glv_shard_*) for the protocol."""
+        self._check(S_local, (self.n_bins,), "S_local")
+        if S_local.dim() != 2:
+            raise ValueError("S_local must be (T_local, F)")
+        t_local = S_local.shape[0]
+        if phase0 is not None:
+            self._check(phase0, (t_local, self.n_bins, 2), "phase0")
+        _lib.check(self.lib.glv_shard_begin(self._handle, _ptr(S_local), _ptr(phase0), int(seed) & (2**64 - 1),
+                                            int(frame_begin), int(t_local), int(frames_global),
+                                            _stream_ptr(self.device)))
+        n = int(self.lib.glv_shard_halo_samples(self._handle))
+        if getattr(self, "_halo", None) is None or self._halo[0].numel() != n:
+            self._halo = tuple(torch.zeros((n,), dtype=torch.float32, device=self.device) for _ in range(4))
+
+    def shard_step(self, momentum=0.99):
+        _lib.check(self.lib.glv_shard_step(self._handle, float(momentum), _stream_ptr(self.device)))
+
+    def shard_halo_pack(self):
+        """Returns (to_prev, to_next): the n_fft - hop partial sums each neighbour needs."""
+        to_prev, to_next = self._halo[0], self._halo[1]
+        _lib.check(self.lib.glv_shard_halo_pack(self._handle, _ptr(to_prev), _ptr(to_next),
+                                                _stream_ptr(self.device)))
+        return to_prev, to_next
+
+    def shard_halo_buffers(self):
+        """(from_prev, from_next) receive buffers to fill before shard_halo_unpack."""
+        return self._halo[2], self._halo[3]
+
+    def shard_halo_unpack(self, from_prev=None, from_next=None):
+        from_prev = self._halo[2] if from_prev is None else from_prev
+        from_next = self._halo[3] if from_next is None else from_next
+        _lib.check(self.lib.glv_shard_halo_unpack(self._handle, _ptr(from_prev), _ptr(from_next),
+                                                  _stream_ptr(self.device)))
+
+    def shard_end(self):
+        """Returns (y_local, n_begin): this shard's samples [n_begin, n_begin + len(y_local))
+        of the whole (un-normalised) waveform."""
+        n_begin, n_count = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self.lib.glv_shard_output_range(self._handle, ctypes.byref(n_begin), ctypes.byref(n_count)))
+        y = torch.empty((max(int(n_count.value), 1),), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_shard_end(self._handle, _ptr(y), _stream_ptr(self.device)))
+        return y[: int(n_count.value)], int(n_begin.value)
+
     def stft(self, y, n_frames=None):
         """(B, hop*(T-1)) -> (B, T, F, 2); librosa.stft(center=True, pad_mode='constant')."""
         self._check(y, (y.shape[-1],), "y")
