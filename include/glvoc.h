@@ -79,6 +79,22 @@ int glv_mel_invert(glv_plan* plan, const float* mel_db_dev, int batch, int frame
                    float mean, float std, float* S_dev, void* stream);
 
 /*
+ * Non-negative inversion, the mel_to_stft step of librosa.feature.inverse.mel_to_audio
+ * that the reference's older scripts call (test_cnn_model.py:117-119, test_1.py:52-54,
+ * z_AR/test_AR_model.py:12-14):
+ *     X = argmin_{X >= 0} 0.5 * || basis @ X - mel ||^2 ,  S = X ** (1 / power)
+ * started from librosa's X0 = max(pinv @ mel, 0) and advanced by n_steps projected-gradient
+ * steps X <- max(X - step * basis^T (basis X - mel), 0) (librosa runs L-BFGS-B from the same
+ * start; F > n_mels, so the minimiser is not unique and only the mel-domain residual is
+ * comparable between solvers).  step should be 1 / ||basis||_2^2.
+ *   glv_plan_set_mel_basis: (n_mels, F) row-major float32 librosa.filters.mel matrix.
+ *   mel_dev: (batch, frames_stride, n_mels) mel POWER values (not dB); S_dev as glv_mel_invert.
+ */
+int glv_plan_set_mel_basis(glv_plan* plan, const float* basis_MxF_host);
+int glv_mel_invert_nnls(glv_plan* plan, const float* mel_dev, int batch, int frames_stride,
+                        int n_steps, float step, float power, float* S_dev, void* stream);
+
+/*
  * librosa.griffinlim(S, n_iter, hop_length, win_length, momentum, init='random')
  * as called at reference vocoder/mel_audio.py:126 (window='hann', center=True,
  * pad_mode='constant').

@@ -302,3 +302,36 @@ def test_time_sharded_equals_single_device(voc, O, lj001, n_fft, hop, frames, sh
     assert max(peaks) == float(np.max(np.abs(y)))
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("n_fft,n_mels", [(1024, 80), (2048, 128)])
+def test_nnls_inversion(voc, O, n_fft, n_mels):
+    """Secondary mode (librosa.feature.inverse.mel_to_audio): the deterministic start
+    clip(pinv @ M, 0) matches exactly to rounding, the projected-gradient iterate matches the
+    oracle's, and the mel-domain residual falls."""
+    rng = np.random.default_rng(13)
+    frames, sr = 50, 22050
+    basis = O.mel_filterbank(sr, n_fft, n_mels=n_mels)
+    truth = (rng.standard_normal((n_fft // 2 + 1, frames)) ** 2).astype(np.float32)
+    m = (basis @ truth).astype(np.float32)                      # (n_mels, T) power mel
+    plan = voc.GriffinLimPlan(n_fft, n_fft // 4, n_fft, n_mels, frames, 1)
+    plan.set_mel_basis(sr, 0.0, None)
+    md = dev(np.ascontiguousarray(m.T[None]))
+    x0 = plan.mel_invert_nnls(md, n_steps=0, power=1.0).cpu().numpy()[0].T
+    assert rel_l2(x0, O.nnls_init(basis, m)) < 1e-5
+    res0 = np.linalg.norm(basis @ x0 - m) / np.linalg.norm(m)
+    x = plan.mel_invert_nnls(md, n_steps=100, power=1.0).cpu().numpy()[0].T
+    want = O.nnls_projected_gradient(basis, m, n_steps=100)
+    assert np.all(x >= 0)
+    assert rel_l2(x, want) < 1e-4
+    res = np.linalg.norm(basis @ x - m) / np.linalg.norm(m)
+    assert res < 0.5 * res0 and res < 0.05
+    # power = 2 takes the square root (magnitude from power)
+    s = plan.mel_invert_nnls(md, n_steps=100, power=2.0).cpu().numpy()[0].T
+    assert rel_l2(s, np.sqrt(want)) < 1e-4
+    plan.close()
+    # the secondary entry point end to end, librosa defaults (hop = n_fft/4, no peak normalisation)
+    y = voc.mel_to_audio(m, sr=sr, n_fft=n_fft, n_iter=4, n_steps=50, init_phase=5)
+    ref = O.mel_to_audio(m, sr=sr, n_fft=n_fft, n_iter=4, n_steps=50, random_state=5)
+    assert y.shape == ref.shape == ((n_fft // 4) * (frames - 1),)
+    assert rel_l2(y, ref) < 1e-3

@@ -247,18 +247,24 @@ __global__ void sc_reduce_kernel(const float* partial, int n_runs, const int* ru
     sc[(int64_t)b * n_iter + k] = sqrtf(num / den);
 }
 
-// S[row][f] = sum_m pinv[f][m] * 10^(0.1*(mel[row][m]*std + mean)).
-// Block = 4 waves, tile 64 rows x 64 bins, each wave one 32x32 f32 MFMA tile;
-// the mel rows are converted to power while being staged into LDS.
+// C[row][col] = epilogue( sum_k load(X[row][k]) * W[col][k] ): an "NT" GEMM on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain).  Block = 4 waves, tile 64 rows x 64 cols,
+// each wave one 32x32 accumulator; operands are staged through LDS in k-chunks of 32.
+//   LOAD_DB    X holds normalised dB; it is converted to power while being staged:
+//              10^(0.1*(x*std + mean)) with numpy's rounding sequence (mel inversion)
+//   EPI_STORE  C = acc                     EPI_CLAMP  C = max(acc, 0)
+//   EPI_SUB    C = acc - D                 EPI_STEP   C = max(D - step*acc, 0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMelKC = 32;  // k-chunk staged per step
+constexpr int kGemmKC = 32;
+enum { EPI_STORE = 0, EPI_CLAMP = 1, EPI_SUB = 2, EPI_STEP = 3 };
 
-__global__ __launch_bounds__(256) void mel_invert_kernel(const float* __restrict__ mel,
-                                                         const float* __restrict__ pinv, int64_t rows,
-                                                         int M, int F, float mean, float std_,
-                                                         float* __restrict__ S) {
-    __shared__ float sa[64][kMelKC + 1];
-    __shared__ float sb[64][kMelKC + 1];
+template <bool LOAD_DB, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ X,
+                                                      const float* __restrict__ W, int64_t rows, int K,
+                                                      int cols, float mean, float std_, float step,
+                                                      const float* D, float* C) {
+    __shared__ float sa[64][kGemmKC + 1];
+    __shared__ float sb[64][kGemmKC + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row0 = (int64_t)blockIdx.y * 64;
     const int col0 = blockIdx.x * 64;
@@ -266,24 +272,27 @@ __global__ __launch_bounds__(256) void mel_invert_kernel(const float* __restrict
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int m0 = 0; m0 < M; m0 += kMelKC) {
-        for (int i = threadIdx.x; i < 64 * kMelKC; i += 256) {
-            const int r = i / kMelKC, k = i % kMelKC;
+    for (int k0 = 0; k0 < K; k0 += kGemmKC) {
+        for (int i = threadIdx.x; i < 64 * kGemmKC; i += 256) {
+            const int r = i / kGemmKC, k = i % kGemmKC;
             float pa = 0.f, pb = 0.f;
-            if (m0 + k < M) {
+            if (k0 + k < K) {
                 if (row0 + r < rows) {
-                    // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
-                    const float x = __fadd_rn(__fmul_rn(mel[(row0 + r) * M + m0 + k], std_), mean);
-                    pa = powf(10.0f, __fmul_rn(0.1f, x));
+                    pa = X[(row0 + r) * K + k0 + k];
+                    if (LOAD_DB) {
+                        // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
+                        const float x = __fadd_rn(__fmul_rn(pa, std_), mean);
+                        pa = powf(10.0f, __fmul_rn(0.1f, x));
+                    }
                 }
-                if (col0 + r < F) pb = pinv[(int64_t)(col0 + r) * M + m0 + k];
+                if (col0 + r < cols) pb = W[(int64_t)(col0 + r) * K + k0 + k];
             }
             sa[r][k] = pa;
             sb[r][k] = pb;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kMelKC; k += 2) {
+        for (int k = 0; k < kGemmKC; k += 2) {
             const float av = sa[wr * 32 + (lane & 31)][k + (lane >> 5)];
             const float bv = sb[wc * 32 + (lane & 31)][k + (lane >> 5)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
@@ -294,8 +303,21 @@ __global__ __launch_bounds__(256) void mel_invert_kernel(const float* __restrict
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int64_t row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < rows && col < F) S[row * F + col] = acc[reg];
+        if (row < rows && col < cols) {
+            const int64_t at = row * cols + col;
+            float v = acc[reg];
+            if (EPI == EPI_CLAMP) v = fmaxf(v, 0.f);
+            if (EPI == EPI_SUB) v = v - D[at];
+            if (EPI == EPI_STEP) v = fmaxf(D[at] - step * v, 0.f);
+            C[at] = v;
+        }
     }
+}
+
+// x -> x^(1/power), in place (librosa.feature.inverse.mel_to_stft's last step)
+__global__ void root_kernel(float* x, int64_t n, float inv_power) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = (inv_power == 0.5f) ? sqrtf(x[i]) : powf(x[i], inv_power);
 }
 
 }  // namespace
@@ -319,6 +341,10 @@ struct glv_plan {
     float* d_iwss_tail = nullptr;
     float* d_pinv = nullptr;
     bool have_pinv = false;
+    float* d_basis = nullptr;    // (n_mels, F) mel basis, NNLS mode
+    float* d_basis_t = nullptr;  // (F, n_mels)
+    float* d_resid = nullptr;    // (rows, n_mels) residual A X - B
+    bool have_basis = false;
     // device workspace
     cf* d_spec = nullptr;
     float* d_S = nullptr;
@@ -445,7 +471,7 @@ void plan_free(glv_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
@@ -642,6 +668,9 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(dmalloc(p, &p->d_iwss_head, tab.iwss_head.size()));
     PLAN_TRY(dmalloc(p, &p->d_iwss_tail, tab.iwss_tail.size()));
     PLAN_TRY(dmalloc(p, &p->d_pinv, (size_t)p->F * n_mels));
+    PLAN_TRY(dmalloc(p, &p->d_basis, (size_t)p->F * n_mels));
+    PLAN_TRY(dmalloc(p, &p->d_basis_t, (size_t)p->F * n_mels));
+    PLAN_TRY(dmalloc(p, &p->d_resid, frames * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_spec, frames * p->P));
     PLAN_TRY(dmalloc(p, &p->d_S, frames * (p->P + 4)));
     for (int i = 0; i < 2; ++i) {
@@ -722,8 +751,53 @@ extern "C" int glv_mel_invert(glv_plan* p, const float* mel_db_dev, int batch, i
     DeviceGuard guard(p->device);
     const int64_t rows = (int64_t)batch * frames_stride;
     const dim3 grid((p->F + 63) / 64, (unsigned)((rows + 63) / 64));
-    hipLaunchKernelGGL(mel_invert_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel_db_dev, p->d_pinv,
-                       rows, p->n_mels, p->F, mean, std_, S_dev);
+    hipLaunchKernelGGL((gemm_nt_kernel<true, EPI_STORE>), grid, dim3(256), 0, (hipStream_t)stream, mel_db_dev,
+                       p->d_pinv, rows, p->n_mels, p->F, mean, std_, 0.f, (const float*)nullptr, S_dev);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+
+extern "C" int glv_plan_set_mel_basis(glv_plan* p, const float* basis_host) {
+    if (!p || !basis_host) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    std::vector<float> t((size_t)p->F * p->n_mels);
+    for (int m = 0; m < p->n_mels; ++m)
+        for (int f = 0; f < p->F; ++f) t[(size_t)f * p->n_mels + m] = basis_host[(size_t)m * p->F + f];
+    HIP_TRY(hipMemcpy(p->d_basis, basis_host, sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_basis_t, t.data(), sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
+    p->have_basis = true;
+    return GLV_OK;
+}
+
+extern "C" int glv_mel_invert_nnls(glv_plan* p, const float* mel_dev, int batch, int frames_stride,
+                                   int n_steps, float step, float power, float* S_dev, void* stream) {
+    if (!p || !mel_dev || !S_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (!p->have_pinv || !p->have_basis)
+        return fail(GLV_ERR_STATE, "glv_plan_set_inverse_basis and glv_plan_set_mel_basis must be called first");
+    if (batch < 1 || frames_stride < 1 || (int64_t)batch * frames_stride > (int64_t)p->max_batch * p->max_frames)
+        return fail(GLV_ERR_INVALID, "batch x frames_stride exceeds the plan's capacity");
+    if (n_steps < 0 || !(step > 0.f) || !(power > 0.f))
+        return fail(GLV_ERR_INVALID, "n_steps >= 0, step > 0 and power > 0 are required");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)batch * frames_stride;
+    const int M = p->n_mels, F = p->F;
+    const dim3 grid_f((F + 63) / 64, (unsigned)((rows + 63) / 64));
+    const dim3 grid_m((M + 63) / 64, (unsigned)((rows + 63) / 64));
+    // X0 = max(pinv @ B, 0): the deterministic start of librosa.util.nnls
+    hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_CLAMP>), grid_f, dim3(256), 0, st, mel_dev, p->d_pinv, rows, M, F,
+                       0.f, 0.f, 0.f, (const float*)nullptr, S_dev);
+    for (int i = 0; i < n_steps; ++i) {
+        // R = X A^T - B   (rows x M), then X = max(X - step * R A, 0)
+        hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_SUB>), grid_m, dim3(256), 0, st, S_dev, p->d_basis, rows, F, M,
+                           0.f, 0.f, 0.f, mel_dev, p->d_resid);
+        hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_STEP>), grid_f, dim3(256), 0, st, p->d_resid, p->d_basis_t, rows,
+                           M, F, 0.f, 0.f, step, S_dev, S_dev);
+    }
+    if (power != 1.0f)
+        hipLaunchKernelGGL(root_kernel, dim3(grid_for(rows * F, 256)), dim3(256), 0, st, S_dev, rows * F,
+                           1.0f / power);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

@@ -58,3 +58,14 @@ def inverse_mel_basis(sr, n_fft, n_mels, fmin, fmax):
     inv = np.ascontiguousarray(np.linalg.pinv(basis), dtype=np.float32)
     inv.setflags(write=False)
     return inv
+
+
+@functools.lru_cache(maxsize=32)
+def mel_basis_and_step(sr, n_fft, n_mels, fmin, fmax):
+    """(basis float32 (n_mels, F), step) for the projected-gradient non-negative inversion:
+    step = 1 / ||basis||_2^2, the reciprocal Lipschitz constant of the gradient of
+    0.5 * ||basis @ X - mel||^2."""
+    basis = np.ascontiguousarray(mel_filterbank(sr, n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax))
+    step = float(1.0 / np.linalg.norm(basis.astype(np.float64), 2) ** 2)
+    basis.setflags(write=False)
+    return basis, step

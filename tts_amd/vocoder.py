@@ -20,9 +20,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from .filters import inverse_mel_basis
+from .filters import inverse_mel_basis, mel_basis_and_step
 
-__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch"]
+__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch", "mel_to_audio"]
 
 
 def _stream_ptr(device):
@@ -105,8 +105,10 @@ class GriffinLimPlan:
     def set_mel_basis(self, sr, fmin=0.0, fmax=None):
         key = (int(sr), float(fmin), None if fmax is None else float(fmax))
         if key != self._basis_key:
-            self.set_inverse_basis(inverse_mel_basis(int(sr), self.n_fft, self.n_mels, float(fmin),
-                                                     None if fmax is None else float(fmax)))
+            args = (int(sr), self.n_fft, self.n_mels, float(fmin), None if fmax is None else float(fmax))
+            self.set_inverse_basis(inverse_mel_basis(*args))
+            basis, self._nnls_step = mel_basis_and_step(*args)
+            _lib.check(self.lib.glv_plan_set_mel_basis(self._handle, basis.ctypes.data_as(_lib.c_float_p)))
             self._basis_key = key
 
     # -- helpers ---------------------------------------------------------------
@@ -136,6 +138,22 @@ class GriffinLimPlan:
         out = torch.empty((b, t, self.n_bins), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.glv_mel_invert(self._handle, _ptr(mel_db), b, t, float(mean), float(std),
                                            _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def mel_invert_nnls(self, mel_power, n_steps=200, power=2.0):
+        """(B, T, n_mels) mel POWER values -> (B, T, F) non-negative magnitudes: the
+        mel_to_stft step of librosa.feature.inverse.mel_to_audio (reference
+        test_cnn_model.py:117-119) as a projected-gradient solver from librosa's start."""
+        self._check(mel_power, (self.n_mels,), "mel_power")
+        if mel_power.dim() != 3:
+            raise ValueError("mel_power must be (B, T, n_mels)")
+        if self._basis_key is None:
+            raise RuntimeError("set_mel_basis(sr, fmin, fmax) first")
+        b, t, _ = mel_power.shape
+        out = torch.empty((b, t, self.n_bins), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_mel_invert_nnls(self._handle, _ptr(mel_power), b, t, int(n_steps),
+                                                float(self._nnls_step), float(power), _ptr(out),
+                                                _stream_ptr(self.device)))
         return out
 
     def griffinlim(self, S, n_frames=None, phase0=None, seed=0, n_iter=60, momentum=0.99,
@@ -390,3 +408,31 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
     if normalize:
         plan.peak_normalize(y, n_samples)
     return (y, n_samples, sc) if return_sc else (y, n_samples)
+
+
+def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_length=None, power=2.0,
+                 n_iter=32, *, fmin=0.0, fmax=None, n_steps=200, momentum=0.99, init_phase=None,
+                 device=None, return_tensor=False):
+    """``librosa.feature.inverse.mel_to_audio(M, sr=sr)`` as the reference's older scripts call
+    it (test_cnn_model.py:117-119, test_1.py:52-54, z_AR/test_AR_model.py:12-14): (n_mels, T)
+    mel -> non-negative least-squares inversion -> ** (1/power) -> Griffin-Lim with librosa's
+    defaults (n_fft 2048, hop n_fft/4, 32 iterations, fmax sr/2).  No peak normalisation.
+    ``n_steps`` projected-gradient steps replace librosa's L-BFGS-B (same start, same
+    objective)."""
+    mel = mel_spectrogram.detach() if isinstance(mel_spectrogram, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(mel_spectrogram, dtype=np.float32))
+    if mel.dim() != 2:
+        raise ValueError("mel_spectrogram must be (n_mels, T)")
+    n_mels, frames = mel.shape
+    win_length = n_fft if win_length is None else win_length
+    hop_length = win_length // 4 if hop_length is None else hop_length
+    plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
+    plan.set_mel_basis(sr, fmin, fmax)
+    mel_tm = mel.t().to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
+    S = plan.mel_invert_nnls(mel_tm, n_steps=n_steps, power=power)
+    if init_phase is None:
+        seed, phase0 = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]), None
+    else:
+        seed, phase0 = 0, _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
+    y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)[0]
+    return y if return_tensor else y.cpu().numpy()
