@@ -178,7 +178,9 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
  * Tuning and measurement hooks (no counterpart in the reference).
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
  *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
- *                        "timing" (0/1: bracket the iteration loop with hipEvents).
+ *                        "timing" (0/1: bracket the iteration loop with hipEvents),
+ *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue
+ *                        their loads and stores but skip the arithmetic; output is garbage).
  *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration
  *                        kernels of the last glv_griffinlim call took on the
  *                        stream (synchronises on the closing event).

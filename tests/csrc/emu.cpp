@@ -83,7 +83,7 @@ struct Emu {
     std::vector<RunDesc> runs;
     std::vector<unsigned char> flags;
     std::vector<cf> spec;
-    std::vector<float> S_native, ym[2], yt[2], sc_partial;
+    std::vector<float> S_native, ym[2], yt[2], sc_partial, zeros, trash;
     std::vector<int> nf;
     int batch, Ts, blocks;
     LayoutArgs L;
@@ -116,6 +116,11 @@ struct Emu {
         a.iwss = tab.iwss.data();
         a.iwss_head = tab.iwss_head.data();
         a.iwss_tail = tab.iwss_tail.data();
+        a.iwss_small = tab.iwss_small.data();
+        zeros.assign(H, 0.f);
+        trash.assign(H, 0.f);
+        a.zeros = zeros.data();
+        a.trash = trash.data();
         a.tables = tab.fft.data();
         a.inv_n = 1.0f / s.n_fft;
     }
@@ -129,8 +134,8 @@ struct Emu {
         for (int b = 0; b < batch; ++b)
             for (int64_t n = 0; n < y_stride; ++n)
                 finalize_sample(L, ym[buf].data(), yt[buf].data(), flags.data(), blocks, tab.w2.data(),
-                                tab.iwss.data(), tab.iwss_head.data(), tab.iwss_tail.data(), y, y_stride,
-                                b, n);
+                                tab.iwss.data(), tab.iwss_head.data(), tab.iwss_tail.data(),
+                                tab.iwss_small.data(), y, y_stride, b, n);
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,

@@ -335,3 +335,18 @@ def test_nnls_inversion(voc, O, n_fft, n_mels):
     ref = O.mel_to_audio(m, sr=sr, n_fft=n_fft, n_iter=4, n_steps=50, random_state=5)
     assert y.shape == ref.shape == ((n_fft // 4) * (frames - 1),)
     assert rel_l2(y, ref) < 1e-3
+
+
+def test_synthesize_cli_writes_the_reference_style_wav(tmp_path, lj001, O):
+    """test.py:191-194 as a command: mel .npy + stats .npy -> PCM16 wav of hop*(T-1) samples."""
+    from tts_amd import synthesize
+    from tts_amd.wavio import read_wav
+    mel, mean, std = lj001
+    np.save(tmp_path / "mel.npy", mel[:200])
+    np.save(tmp_path / "stats.npy", np.array([mean, std], np.float32))
+    out = tmp_path / "out.wav"
+    synthesize.main(["--mel", str(tmp_path / "mel.npy"), "--stats", str(tmp_path / "stats.npy"),
+                     "--out", str(out), "--seed", "7"])
+    audio, sr = read_wav(out)
+    assert sr == 22050 and audio.shape == (256 * 199,)
+    assert np.max(np.abs(audio)) > 0.9999

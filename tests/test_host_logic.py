@@ -61,3 +61,21 @@ def test_synthetic_mel_is_ljspeech_shaped():
     db = m * STD + MEAN
     assert db.max() == pytest.approx(0.0, abs=1e-3) and db.min() >= -80.001
     assert np.array_equal(m, synthetic_mel(1234, 430))
+
+
+def test_wav_writer_matches_the_reference_files(tmp_path):
+    """PCM16 conversion: the reference's wavs hold +32767 / -32768 peaks for audio
+    normalised to just under 1.0, i.e. scale 32768, round, clip."""
+    from tts_amd.wavio import float_to_pcm16, read_wav, write_wav
+    x = np.array([0.0, 0.5, -0.5, 0.99999, -0.99999, 1.0, -1.0, 1.5, -1.5, 1e-5], np.float32)
+    pcm = float_to_pcm16(x)
+    assert pcm.tolist() == [0, 16384, -16384, 32767, -32768, 32767, -32768, 32767, -32768, 0]
+    path = tmp_path / "t.wav"
+    y = np.sin(np.linspace(0, 100, 5000)).astype(np.float32) * 0.7
+    write_wav(path, y, 22050)
+    back, sr = read_wav(path)
+    assert sr == 22050 and back.shape == y.shape
+    assert np.max(np.abs(back - y)) <= 0.5 / 32768 + 1e-7
+    from scipy.io import wavfile
+    sr2, raw = wavfile.read(str(path))
+    assert sr2 == 22050 and raw.dtype == np.int16 and np.array_equal(raw, float_to_pcm16(y))

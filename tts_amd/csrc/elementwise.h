@@ -80,7 +80,7 @@ GLV_HD void spec_to_natural_element(const LayoutArgs& L, const cf* spec, cf* D_n
 GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const float* y_tail,
                              const unsigned char* tail_flag, int blocks_stride, const float* w2,
                              const float* iwss, const float* iwss_head, const float* iwss_tail,
-                             float* out, int64_t out_stride, int b, int64_t n) {
+                             const float* iwss_small, float* out, int64_t out_stride, int b, int64_t n) {
     const int T = L.n_frames[b];
     const int64_t len = (int64_t)L.hop * (T - 1);
     float val = 0.f;
@@ -90,9 +90,7 @@ GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const flo
         const int64_t at = (int64_t)b * L.y_utt_stride + p;
         if (j < T) val = y_main[at];
         if (tail_flag[(int64_t)b * blocks_stride + j]) val += y_tail[at];
-        const float iw = (j >= L.R - 1 && j <= T - 1)
-                             ? iwss[s]
-                             : edge_iwss_lookup(w2, iwss_head, iwss_tail, L.hop, L.R, T, j, s);
+        const float iw = iwss_row(iwss, iwss_head, iwss_tail, iwss_small, L.hop, L.R, T, j)[s];
         val *= iw;
     }
     out[(int64_t)b * out_stride + n] = val;

@@ -48,7 +48,9 @@ struct RunDesc {
     int utt, t_begin, t_end, n_frames;
 };
 
-enum Mode { MODE_ITER = 0, MODE_ISTFT = 1, MODE_STFT = 2 };
+// MODE_TRAFFIC: the iteration kernel's loads and stores with the arithmetic removed - a
+// measurement aid that gives the memory-system ceiling of this access pattern.
+enum Mode { MODE_ITER = 0, MODE_ISTFT = 1, MODE_STFT = 2, MODE_TRAFFIC = 3 };
 
 struct IterArgs {
     const RunDesc* runs;
@@ -66,6 +68,9 @@ struct IterArgs {
     const float* iwss;        // reciprocal of the complete window-sum-square, H floats
     const float* iwss_head;   // [R-1][H]: blocks 0..R-2 (frames before the first are missing)
     const float* iwss_tail;   // [R-1][H]: blocks T..T+R-2 (frames after the last are missing)
+    const float* iwss_small;  // [R-1][2R][H]: utterances shorter than R-1 frames (both sides missing)
+    const float* zeros;       // H zero floats: source of blocks that do not exist
+    float* trash;             // H floats nobody reads: sink of blocks that do not exist
     const cf* tables;         // twA | twB | twP | win
     float* sc_partial;        // [run][2] (numerator, denominator) or null
     float cmom;               // momentum / (1 + momentum)
@@ -83,20 +88,19 @@ GLV_HD float rcp_refined(float x) {
 #endif
 }
 
-// Reciprocal window-sum-square of sample s of block j when some of the R frames that
-// would cover it do not exist (utterance edges).  Head and tail cases come from host
-// tables; an utterance shorter than R frames can be truncated on both sides at once and
-// is summed here.
-GLV_HD float edge_iwss_lookup(const float* w2, const float* iwss_head, const float* iwss_tail, int H,
-                              int R, int T, int j, int s) {
-    if (j < R - 1 && j <= T - 1) return iwss_head[j * H + s];
-    if (j >= R - 1 && j > T - 1 && j - (T - 1) <= R - 1) return iwss_tail[(j - T) * H + s];
-    int t0 = j - R + 1;
-    if (t0 < 0) t0 = 0;
-    const int t1 = j < T - 1 ? j : T - 1;
-    float sum = 0.f;
-    for (int t = t0; t <= t1; ++t) sum += w2[(j - t) * H + s];
-    return sum > 1.17549435e-38f ? 1.0f / sum : 1.0f;
+// Row (H floats) of reciprocal window-sum-squares for block j of a T-frame utterance.
+// Fully covered blocks share one row; blocks near an utterance edge, where some of the R
+// covering frames do not exist, have rows of their own in host-built tables: `head` for
+// j < R-1, `tail` for j > T-1, `small` when the utterance is so short that both ends are
+// missing at once.  All arguments are wave-uniform, so this is scalar selection.
+GLV_HD const float* iwss_row(const float* iwss, const float* iwss_head, const float* iwss_tail,
+                             const float* iwss_small, int H, int R, int T, int j) {
+    const bool after_head = j >= R - 1, before_tail = j <= T - 1;
+    if (after_head && before_tail) return iwss;
+    if (before_tail) return iwss_head + (int64_t)j * H;
+    if (after_head) return iwss_tail + (int64_t)((j - T) < R - 1 ? (j - T) : R - 2) * H;
+    const int jj = j < 2 * R ? j : 2 * R - 1;
+    return iwss_small + ((int64_t)(T < R - 1 ? T : R - 2) * 2 * R + jj) * H;
 }
 
 template <int A, int HB>
@@ -117,7 +121,6 @@ struct Engine {
     cf raw[kSlide ? E : HB];
     cf acc[E];
     cf v[E];
-    cf iw[HB];
     // loads issued one frame ahead of their use (software prefetch)
     cf tp_n[E];
     float s_n[E];
@@ -138,79 +141,65 @@ struct Engine {
 #pragma unroll
         for (int k0a = 0; k0a < A; ++k0a) mbase[k0a] = G::mirror_base(k0a, lane);
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const cf* q = reinterpret_cast<const cf*>(a.iwss + 128 * i + 2 * lane);
-            iw[i] = *q;
-        }
-#pragma unroll
         for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
         sc_num = 0.f;
         sc_den = 0.f;
     }
 
-    // reciprocal window-sum-square of sample s of block j near an utterance edge
-    GLV_HD float edge_iwss(const IterArgs& a, int j, int s) const {
-        return edge_iwss_lookup(a.w2, a.iwss_head, a.iwss_tail, H, R, run.n_frames, j, s);
-    }
-
     // Block j of the previous iteration's signal is (main + tail) / wss, and zero outside
-    // the signal proper (the zero padding of a centred STFT).  Reading it is split in
-    // two so the loads can be issued a whole frame ahead of their use.
+    // the signal proper (the zero padding of a centred STFT).  Reading it is split in two so
+    // the loads can be issued a whole frame ahead of their use, and it is branch-free:
+    // blocks or parts that do not exist are read from a zero buffer, so the number of memory
+    // operations per frame is constant and the compiler can count them (s_waitcnt vmcnt(N))
+    // instead of draining the queue.
     struct BlockFetch {
         cf main[HB];
         cf tail[HB];
+        cf w[HB];
     };
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
         return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
     }
     GLV_HD void fetch_block(const IterArgs& a, int j, BlockFetch& f) const {
-#pragma unroll
-        for (int i = 0; i < HB; ++i) f.main[i] = f.tail[i] = cf{0.f, 0.f};
-        if (!block_valid(j)) return;
-        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H + 2 * lane;
-        if (a.raw_in || j < run.n_frames) {
-#pragma unroll
-            for (int i = 0; i < HB; ++i) f.main[i] = *reinterpret_cast<const cf*>(a.y_in + base + 128 * i);
-        }
-        if (block_has_tail(a, j)) {
-#pragma unroll
-            for (int i = 0; i < HB; ++i) f.tail[i] = *reinterpret_cast<const cf*>(a.y_in_tail + base + 128 * i);
-        }
-    }
-    GLV_HD void finish_block(const IterArgs& a, int j, const BlockFetch& f, cf* out) const {
-        const bool interior = j >= R - 1 && j <= run.n_frames - 1;
+        const bool valid = block_valid(j);
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
+        const float* pm = (valid && (a.raw_in || j < run.n_frames)) ? a.y_in + base : a.zeros;
+        const float* pt = (valid && block_has_tail(a, j)) ? a.y_in_tail + base : a.zeros;
+        const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
-            cf val = f.main[i] + f.tail[i];
-            if (!a.raw_in && block_valid(j)) {
-                cf w = iw[i];
-                if (!interior) {
-                    w.x = edge_iwss(a, j, 128 * i + 2 * lane);
-                    w.y = edge_iwss(a, j, 128 * i + 2 * lane + 1);
-                }
-                val.x *= w.x;
-                val.y *= w.y;
-            }
-            out[i] = val;
+            f.main[i] = *reinterpret_cast<const cf*>(pm + 128 * i + 2 * lane);
+            f.tail[i] = *reinterpret_cast<const cf*>(pt + 128 * i + 2 * lane);
+            f.w[i] = *reinterpret_cast<const cf*>(pw + 128 * i + 2 * lane);
+        }
+    }
+    GLV_HD void finish_block(const IterArgs& a, const BlockFetch& f, cf* out) const {
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const cf val = f.main[i] + f.tail[i];
+            const float wx = a.raw_in ? 1.0f : f.w[i].x, wy = a.raw_in ? 1.0f : f.w[i].y;
+            out[i] = cf{val.x * wx, val.y * wy};
         }
     }
     GLV_HD void load_block(const IterArgs& a, int j, cf* out) const {
         BlockFetch f;
         fetch_block(a, j, f);
-        finish_block(a, j, f, out);
+        finish_block(a, f, out);
     }
     BlockFetch blk_n;
 
-    // issue the loads frame t will need: its newest signal block ...
+    // issue the loads frame t will need (t clamped into the run: the last frame re-requests
+    // its own data rather than branching): its newest signal block ...
     GLV_HD void prefetch_block(const IterArgs& a, int t) {
-        if (t < run.t_end) fetch_block(a, t + R - 1, blk_n);
+        const int tt = t < run.t_end ? t : run.t_end - 1;
+        fetch_block(a, tt + R - 1, blk_n);
     }
     // ... and its previous spectrum and target magnitudes
     GLV_HD void prefetch_spec(const IterArgs& a, int t) {
-        if (t >= run.t_end) return;
-        if (kPrefetchTp && a.has_prev) load_spec(a, t, tp_n);
-        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+        const int tt = t < run.t_end ? t : run.t_end - 1;
+        load_spec(a, tt, tp_n);
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
             const f4 sq = reinterpret_cast<const f4*>(sf)[q * 64 + lane];
@@ -223,11 +212,9 @@ struct Engine {
     }
 
     GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf* src) const {
-        const int T = run.n_frames;
-        if (j < R / 2 || j >= R / 2 + T - 1) return;
-        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H + 2 * lane;
+        float* p = block_valid(j) ? dst + (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H : a.trash;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) *reinterpret_cast<cf*>(dst + base + 128 * i) = src[i];
+        for (int i = 0; i < HB; ++i) *reinterpret_cast<cf*>(p + 128 * i + 2 * lane) = src[i];
     }
 
     // blocks t_begin .. t_begin+R-2 of the first frame
@@ -240,7 +227,7 @@ struct Engine {
     // ---- phase 0: newest block, window, first DFT pass ----
     GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
         if (kSlide) {
-            finish_block(a, t + R - 1, blk_n, &raw[(R - 1) * HB]);
+            finish_block(a, blk_n, &raw[(R - 1) * HB]);
             prefetch_block(a, t + 1);
 #pragma unroll
             for (int r = 0; r < E; ++r) {
@@ -254,12 +241,7 @@ struct Engine {
 #pragma unroll
             for (int q = 0; q < R - 1; ++q) fetch_block(a, t + q, f[q]);
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                if (q < R - 1)
-                    finish_block(a, t + q, f[q], &v[q * HB]);
-                else
-                    finish_block(a, t + R - 1, blk_n, &v[q * HB]);
-            }
+            for (int q = 0; q < R; ++q) finish_block(a, q < R - 1 ? f[q] : blk_n, &v[q * HB]);
             prefetch_block(a, t + 1);
 #pragma unroll
             for (int r = 0; r < E; ++r) {
@@ -308,7 +290,9 @@ struct Engine {
     GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
-        if (!kPrefetchTp && a.has_prev) load_spec(a, t, tp_n);
+        if (!kPrefetchTp) load_spec(a, t, tp_n);
+        // first iteration: no momentum term (tp_n then holds the initial angles, times zero)
+        const float cmom = a.has_prev ? a.cmom : 0.0f;
         F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
         store_spec(a, t);
 #pragma unroll
@@ -323,8 +307,7 @@ struct Engine {
                 sc_num += ex * ex + ey * ey;
                 sc_den += sx * sx + (packed ? sy * sy : 0.f);
             }
-            cf d = x;
-            if (a.has_prev) d = cf{x.x - a.cmom * tp_n[reg].x, x.y - a.cmom * tp_n[reg].y};
+            const cf d = cf{x.x - cmom * tp_n[reg].x, x.y - cmom * tp_n[reg].y};
             const float mag = sqrtf(d.x * d.x + d.y * d.y);
             const float mx = packed ? fabsf(d.x) : mag;
             const float my = packed ? fabsf(d.y) : mag;
@@ -334,6 +317,23 @@ struct Engine {
         }
         prefetch_spec(a, t + 1);
     }
+    // ---- MODE_TRAFFIC: one frame's memory operations, nothing else ----
+    GLV_HD void traffic_frame(const IterArgs& a, int t) {
+        finish_block(a, blk_n, &raw[(R - 1) * HB]);
+        prefetch_block(a, t + 1);
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = cf{raw[r].x + tp_n[r].x * s_n[r], raw[r].y + tp_n[r].y * s_nyq_n};
+#pragma unroll
+        for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
+        store_spec(a, t);
+        prefetch_spec(a, t + 1);
+#pragma unroll
+        for (int q = 0; q < E; ++q) acc[q] = acc[q] + v[q];
+        store_block(a, a.y_out, t, &acc[0]);
+#pragma unroll
+        for (int q = 0; q + HB < E; ++q) acc[q] = acc[q + HB];
+    }
+
     // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
     GLV_HD void ph3_load(const IterArgs& a, int t) { load_spec(a, t, v); }
 

@@ -80,19 +80,30 @@ gl_engine_kernel(IterArgs a) {
     for (int i = threadIdx.x; i < G::TABLES; i += blockDim.x) tables[i] = a.tables[i];
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform values are forced into scalar registers: the compiler cannot see that
+    // threadIdx.x >> 6 (and everything loaded through it) is the same in all 64 lanes
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ri = blockIdx.x * kWavesPerBlock + wave;
     if (ri >= a.n_runs) return;
     cf* xb = tables + G::TABLES + wave * G::XBUF;
 
+    RunDesc rd = a.runs[ri];
+    rd.utt = __builtin_amdgcn_readfirstlane(rd.utt);
+    rd.t_begin = __builtin_amdgcn_readfirstlane(rd.t_begin);
+    rd.t_end = __builtin_amdgcn_readfirstlane(rd.t_end);
+    rd.n_frames = __builtin_amdgcn_readfirstlane(rd.n_frames);
     Eng e;
-    e.init(a, tables, lane, a.runs[ri]);
+    e.init(a, tables, lane, rd);
     if (MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
     }
-    if (MODE == MODE_ITER) e.prefetch_spec(a, e.run.t_begin);
+    if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     for (int t = e.run.t_begin; t < e.run.t_end; ++t) {
+        if (MODE == MODE_TRAFFIC) {
+            e.traffic_frame(a, t);
+            continue;
+        }
         if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
             wave_sync();
@@ -189,14 +200,14 @@ __global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride,
 __global__ void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
                                 const unsigned char* tail_flag, int blocks_stride, const float* w2,
                                 const float* iwss, const float* iwss_head, const float* iwss_tail,
-                                float* out, int64_t out_stride, int64_t n_begin) {
+                                const float* iwss_small, float* out, int64_t out_stride, int64_t n_begin) {
     // samples [n_begin, n_begin + out_stride) of every row; pointers of a time shard are
     // pre-shifted so that global sample / block indices address them
     const int b = blockIdx.y;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
          n += (int64_t)gridDim.x * blockDim.x)
-        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head, iwss_tail, out,
-                        out_stride, b, n_begin + n);
+        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head, iwss_tail,
+                        iwss_small, out, out_stride, b, n_begin + n);
 }
 
 __global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_t y_stride,
@@ -333,12 +344,15 @@ struct glv_plan {
     int wave_slots = 2048;   // runs the device holds at once (CUs x resident blocks x waves)
     int use_graph = 1;
     int timing = 0;
+    int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
     // device tables
     cf* d_tables = nullptr;
     float* d_w2 = nullptr;
     float* d_iwss = nullptr;
     float* d_iwss_head = nullptr;
     float* d_iwss_tail = nullptr;
+    float* d_iwss_small = nullptr;
+    float* d_zeros = nullptr;  // hop zeros followed by hop floats of write-only trash
     float* d_pinv = nullptr;
     bool have_pinv = false;
     float* d_basis = nullptr;    // (n_mels, F) mel basis, NNLS mode
@@ -403,6 +417,8 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, false>), g, b, lds, st, a);
+    } else if (mode == MODE_TRAFFIC) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT, false>), g, b, lds, st, a);
     } else {
@@ -471,7 +487,7 @@ void plan_free(glv_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
@@ -504,6 +520,9 @@ IterArgs iter_args(const glv_plan* p, int frames_stride) {
     a.iwss = p->d_iwss;
     a.iwss_head = p->d_iwss_head;
     a.iwss_tail = p->d_iwss_tail;
+    a.iwss_small = p->d_iwss_small;
+    a.zeros = p->d_zeros;
+    a.trash = p->d_zeros + p->hop;
     a.tables = p->d_tables;
     a.inv_n = 1.0f / (float)p->n_fft;
     return a;
@@ -667,6 +686,11 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(dmalloc(p, &p->d_iwss, tab.iwss.size()));
     PLAN_TRY(dmalloc(p, &p->d_iwss_head, tab.iwss_head.size()));
     PLAN_TRY(dmalloc(p, &p->d_iwss_tail, tab.iwss_tail.size()));
+    PLAN_TRY(dmalloc(p, &p->d_iwss_small, tab.iwss_small.size()));
+    PLAN_TRY(dmalloc(p, &p->d_zeros, (size_t)2 * hop));
+    PLAN_TRY(hipMemset(p->d_zeros, 0, sizeof(float) * 2 * hop));
+    PLAN_TRY(hipMemcpy(p->d_iwss_small, tab.iwss_small.data(), tab.iwss_small.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
     PLAN_TRY(dmalloc(p, &p->d_pinv, (size_t)p->F * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_basis, (size_t)p->F * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_basis_t, (size_t)p->F * n_mels));
@@ -720,6 +744,12 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->use_graph = value != 0;
     } else if (!strcmp(name, "timing")) {
         p->timing = value != 0;
+    } else if (!strcmp(name, "traffic_only")) {
+        p->traffic_only = value != 0;
+        if (p->graph_exec) {
+            (void)hipGraphExecDestroy(p->graph_exec);
+            p->graph_exec = nullptr;
+        }
     } else {
         return fail(GLV_ERR_INVALID, "unknown option '%s'", name);
     }
@@ -813,7 +843,7 @@ int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool wi
         a.has_prev = k > 0;
         a.sc_partial = with_sc ? p->d_sc_partial + (size_t)k * p->n_runs * 2 : nullptr;
         set_io(p, a, cur, cur ^ 1);
-        HIP_TRY(p->launch_engine(MODE_ITER, with_sc, a, engine_grid(p), st));
+        HIP_TRY(p->launch_engine(p->traffic_only ? MODE_TRAFFIC : MODE_ITER, with_sc, a, engine_grid(p), st));
         cur ^= 1;
     }
     return GLV_OK;
@@ -904,7 +934,7 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
     const int last = n_iter & 1;
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
-                       p->d_iwss_tail, y_dev, y_stride, (int64_t)0);
+                       p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0);
     HIP_TRY(hipGetLastError());
     if (with_sc) {
         hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
@@ -1087,7 +1117,8 @@ extern "C" int glv_shard_end(glv_plan* p, float* y_dev, void* stream) {
         const int cur = p->shard_cur;
         hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(n_count, 256), 1), dim3(256), 0, (hipStream_t)stream,
                            ea, p->d_ym[cur] - off, p->d_yt[cur] - off, p->d_flags - p->shard_t0, p->blocks,
-                           p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, y_dev - n_begin, n_count, n_begin);
+                           p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev - n_begin,
+                           n_count, n_begin);
         HIP_TRY(hipGetLastError());
     }
     p->shard_active = false;
@@ -1195,7 +1226,7 @@ extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_ho
     HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail,
-                       y_dev, y_stride, (int64_t)0);
+                       p->d_iwss_small, y_dev, y_stride, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

@@ -19,6 +19,7 @@ struct HostTables {
     std::vector<float> iwss;  // reciprocal complete window-sum-square, H
     std::vector<float> iwss_head;  // [R-1][H] blocks 0..R-2: only frames 0..j exist
     std::vector<float> iwss_tail;  // [R-1][H] blocks T..T+R-2: frames past T-1 are missing
+    std::vector<float> iwss_small;  // [R-1][2R][H] indexed [T][j]: utterances of T <= R-2 frames
 };
 
 // Periodic Hann window of win_length, zero-padded centrally to n_fft
@@ -90,6 +91,18 @@ HostTables build_tables(int hop, int win_length) {
             for (int u = R - 1; u >= d; --u) acc = (float)((double)acc + w[u * hop + s] * w[u * hop + s]);
             t.iwss_tail[(size_t)(d - 1) * hop + s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
         }
+    // very short utterances (T <= R-2): a block can miss frames on both sides at once
+    const int rows = std::max(1, R - 1);
+    t.iwss_small.assign((size_t)rows * 2 * R * hop, 1.0f);
+    for (int T = 1; T <= R - 2; ++T)
+        for (int j = 0; j < 2 * R; ++j)
+            for (int s = 0; s < hop; ++s) {
+                float acc = 0.f;
+                const int t0 = std::max(0, j - R + 1), t1 = std::min(T - 1, j);
+                for (int tt = t0; tt <= t1; ++tt)
+                    acc = (float)((double)acc + w[(j - tt) * hop + s] * w[(j - tt) * hop + s]);
+                t.iwss_small[((size_t)T * 2 * R + j) * hop + s] = acc > FLT_MIN ? 1.0f / acc : 1.0f;
+            }
     return t;
 }
 
