@@ -21,11 +21,11 @@ def find(outdir, sub, suffix):
 
 
 def short(name):
-    for key in ("gl_engine_kernel", "mel_invert_kernel", "init_native_kernel", "finalize_kernel",
+    for key in ("gl_engine_kernel", "gemm_nt_kernel", "root_kernel", "mel_invert_kernel", "init_native_kernel", "finalize_kernel",
                 "peak_reduce_kernel", "peak_scale_kernel", "sc_reduce_kernel", "spec_convert_kernel",
                 "pad_signal_kernel"):
         if key in name:
-            if key == "gl_engine_kernel":
+            if key in ("gl_engine_kernel", "gemm_nt_kernel"):
                 # template args <A, HB, MODE, SC>
                 tail = name[name.index(key):]
                 return tail[: tail.index(">") + 1] if ">" in tail else tail[:60]

@@ -28,15 +28,16 @@
 #include "wave_fft.h"
 
 // Build-time tuning switches for the 16-values-per-lane engine (n_fft 2048), whose
-// register budget is tight: 1 = as for n_fft 1024 (slide the STFT input in registers,
-// fetch the previous spectrum a frame ahead).  Measured on MI355X at 64 x 865 frames:
-// both on with one wave per SIMD 370-389 us per iteration; either off, or two waves per
-// SIMD forced by the launch bound (scratch spills), 470-640 us.
+// register budget is tight: 1 = as for n_fft 1024 (slide the STFT input in registers /
+// fetch the previous spectrum a frame ahead).  Measured on MI355X at 64 x 865 frames, us
+// per iteration: one wave per SIMD with both on 362; two waves per SIMD (launch bound 2,
+// a few registers spilled) with both on 372, without sliding 367, without the spectrum
+// prefetch 343 - the default.
 #ifndef GLV_SLIDE_ALL
 #define GLV_SLIDE_ALL 1
 #endif
 #ifndef GLV_PREFETCH_TP_ALL
-#define GLV_PREFETCH_TP_ALL 1
+#define GLV_PREFETCH_TP_ALL 0
 #endif
 namespace glv {
 
@@ -198,7 +199,7 @@ struct Engine {
     // ... and its previous spectrum and target magnitudes
     GLV_HD void prefetch_spec(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
-        load_spec(a, tt, tp_n);
+        if (kPrefetchTp) load_spec(a, tt, tp_n);
         const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
@@ -319,12 +320,13 @@ struct Engine {
     }
     // ---- MODE_TRAFFIC: one frame's memory operations, nothing else ----
     GLV_HD void traffic_frame(const IterArgs& a, int t) {
-        finish_block(a, blk_n, &raw[(R - 1) * HB]);
+        cf nb[HB];
+        finish_block(a, blk_n, nb);
         prefetch_block(a, t + 1);
+        if (!kPrefetchTp) load_spec(a, t, tp_n);
 #pragma unroll
-        for (int r = 0; r < E; ++r) v[r] = cf{raw[r].x + tp_n[r].x * s_n[r], raw[r].y + tp_n[r].y * s_nyq_n};
-#pragma unroll
-        for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
+        for (int r = 0; r < E; ++r)
+            v[r] = cf{nb[r % HB].x + tp_n[r].x * s_n[r], nb[r % HB].y + tp_n[r].y * s_nyq_n};
         store_spec(a, t);
         prefetch_spec(a, t + 1);
 #pragma unroll

@@ -68,7 +68,7 @@ __device__ __forceinline__ void wave_sync() {
 #define GLV_MIN_WAVES_A1 2
 #endif
 #ifndef GLV_MIN_WAVES_A2
-#define GLV_MIN_WAVES_A2 1
+#define GLV_MIN_WAVES_A2 2
 #endif
 template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
@@ -567,7 +567,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
             max_t = std::max(max_t, n_frames_host[b]);
         }
         const int64_t slots = p->wave_slots;
-        const int64_t rounds = std::max<int64_t>(1, (total + slots * 20 - 1) / (slots * 20));
+        const int64_t rounds = std::max<int64_t>(1, (total + slots * 64 - 1) / (slots * 64));
         const int64_t cap = slots * rounds;
         int fpr = (int)std::max<int64_t>(std::max(1, p->R - 1), (total + cap - 1) / cap);
         for (;; ++fpr) {
