@@ -142,6 +142,25 @@ int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int 
               int frames_stride, float* y_dev, int64_t y_stride, void* stream);
 
 /*
+ * The forward direction, as the reference's preprocessing computes its training mels
+ * (acoustic/dataset.py:75-84): librosa.feature.melspectrogram (|stft|^2 @ mel basis) and
+ * librosa.power_to_db.  Same transform kernels as the vocoder; lets a wav -> mel -> wav round
+ * trip stay on the device.
+ *   glv_melspectrogram: y_dev (batch, y_stride) with hop*(n_frames[b]-1) samples per row ->
+ *                       mel_dev (batch, frames_stride, n_mels) power values; needs
+ *                       glv_plan_set_mel_basis.
+ *   glv_power_to_db   : rows of n_valid_host[b] values -> 10*log10(max(amin, x)) -
+ *                       10*log10(max(amin, ref)), ref = the row maximum (ref_is_max, i.e.
+ *                       ref=np.max) or ref_value; then floored at (row maximum - top_db) unless
+ *                       top_db < 0.  librosa defaults: amin 1e-10, top_db 80.
+ */
+int glv_melspectrogram(glv_plan* plan, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+                       int batch, int frames_stride, float* mel_dev, void* stream);
+int glv_power_to_db(glv_plan* plan, const float* x_dev, const int* n_valid_host, int batch,
+                    int64_t stride, int ref_is_max, float ref_value, float amin, float top_db,
+                    float* out_dev, void* stream);
+
+/*
  * Time-sharded librosa.griffinlim (reference vocoder/mel_audio.py:126) for one utterance
  * too long for, or wanted faster than, one GPU: this device holds frames
  * [frame_begin, frame_begin + frames_local) of frames_global.  The reference has no

@@ -47,7 +47,7 @@ __all__ = [
     "hann_window", "pad_center", "window_sumsquare", "stft", "istft",
     "spectral_convergence", "griffinlim", "peak_normalise", "mel_invert",
     "mel_to_audio_griffin_lim", "nnls_init", "nnls_projected_gradient",
-    "mel_to_stft", "mel_to_audio",
+    "mel_to_stft", "mel_to_audio", "melspectrogram", "power_to_db",
 ]
 
 
@@ -350,3 +350,27 @@ def mel_to_audio(m, sr=22050, n_fft=2048, hop_length=None, win_length=None, powe
     s = mel_to_stft(m, sr=sr, n_fft=n_fft, power=power, n_steps=n_steps, **kw)
     return griffinlim(s, n_iter=n_iter, hop_length=hop_length, win_length=win_length,
                       n_fft=n_fft, init_phase=init_phase, random_state=random_state)
+
+
+# ----------------------------------------------------------------------------
+# forward direction: the reference's mel extraction, acoustic/dataset.py:75-84
+# ----------------------------------------------------------------------------
+def melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, win_length=None, power=2.0, n_mels=128,
+                   fmin=0.0, fmax=None):
+    """librosa.feature.melspectrogram(y=...): |stft|**power contracted with the mel basis."""
+    d = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length)
+    s = np.abs(d) ** power
+    basis = mel_filterbank(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
+    return np.einsum("ft,mf->mt", s, basis, optimize=True)
+
+
+def power_to_db(s, ref=1.0, amin=1e-10, top_db=80.0):
+    """librosa.power_to_db."""
+    s = np.asarray(s)
+    magnitude = s
+    ref_value = ref(magnitude) if callable(ref) else np.abs(ref)
+    log_spec = 10.0 * np.log10(np.maximum(amin, magnitude))
+    log_spec -= 10.0 * np.log10(np.maximum(amin, ref_value))
+    if top_db is not None:
+        log_spec = np.maximum(log_spec, log_spec.max() - top_db)
+    return log_spec

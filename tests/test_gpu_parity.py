@@ -350,3 +350,35 @@ def test_synthesize_cli_writes_the_reference_style_wav(tmp_path, lj001, O):
     audio, sr = read_wav(out)
     assert sr == 22050 and audio.shape == (256 * 199,)
     assert np.max(np.abs(audio)) > 0.9999
+
+
+def test_forward_mel_extraction_and_round_trip(voc, O, lj001):
+    """acoustic/dataset.py:75-84 on the device, and the loop it closes: mel -> wav -> mel."""
+    mel, mean, std = lj001
+    rng = np.random.default_rng(17)
+    y = (rng.standard_normal(256 * 120) * np.hanning(256 * 120)).astype(np.float32)
+    for n_fft in (2048, 1024):
+        got = voc.audio_to_mel_db(y, n_fft=n_fft, win_length=n_fft)
+        ms = O.melspectrogram(y, sr=22050, n_fft=n_fft, hop_length=256, win_length=n_fft, n_mels=80, fmax=8000)
+        want = O.power_to_db(ms, ref=np.max).T
+        assert got.shape == want.shape == (121, 80) and got.dtype == np.float32
+        assert got.max() == pytest.approx(0.0, abs=1e-4) and got.min() >= -80.0001
+        assert np.max(np.abs(got - want)) < 2e-3          # dB
+        plan = voc.get_plan(n_fft, 256, n_fft, 80, 121, 1)
+        mp = plan.melspectrogram(dev(y[None])).cpu().numpy()[0]
+        assert rel_l2(mp, ms.T) < 1e-4
+    # Round trip mel -> wav -> mel.  (Through the reference's own function it would not close:
+    # mel_audio.py feeds pinv(basis) @ POWER mel to Griffin-Lim as if it were a magnitude, so
+    # the re-analysed dB range doubles.  librosa's mel_to_audio takes the square root and
+    # does close, up to Griffin-Lim's inconsistency.)
+    speech = voc.mel_to_audio_griffin_lim(mel[:300], mean, std, init_phase=1)
+    plan = voc.get_plan(2048, 512, 2048, 80, 1 + len(speech) // 512, 1)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    n = 512 * (len(speech) // 512)
+    m0 = plan.melspectrogram(dev(speech[None, :n])).cpu().numpy()[0].T          # (80, T) power
+    audio = voc.mel_to_audio(m0, sr=22050, n_fft=2048, fmax=8000, n_iter=32, n_steps=100, init_phase=2)
+    assert audio.shape == (n,)
+    m1 = plan.melspectrogram(dev(audio[None])).cpu().numpy()[0].T
+    db0, db1 = O.power_to_db(m0, ref=np.max), O.power_to_db(m1, ref=m0.max())
+    loud = db0 > -40
+    assert np.mean(np.abs(db1[loud] - db0[loud])) < 3.0                          # dB

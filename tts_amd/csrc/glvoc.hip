@@ -325,6 +325,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+// native spectrum -> natural-order power |D|^2, (rows, F) float32 (librosa's _spectrogram, power=2)
+template <int A>
+__global__ void spec_power_kernel(ElemArgs ea, const cf* spec, float* power) {
+    const int P = ea.L.P, F = ea.L.F;
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % P);
+        const int64_t fr = i / P;
+        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
+        const bool live = t < ea.L.n_frames[b];
+        const int reg = q >> 6, lane = q & 63;
+        const int k = Geo<A>::bin(reg, lane);
+        const cf d = live ? spec[fr * P + native_spec_index(reg, lane)] : cf{0.f, 0.f};
+        if (q == 0) {
+            power[fr * F] = d.x * d.x;       // DC and Nyquist share native bin 0
+            power[fr * F + P] = d.y * d.y;
+        } else {
+            power[fr * F + k] = d.x * d.x + d.y * d.y;
+        }
+    }
+}
+
+// librosa.power_to_db: 10*log10(max(amin, x)) - 10*log10(max(amin, ref)), floored at
+// (its own maximum - top_db) when top_db >= 0.  ref is ref_dev[b] (per utterance) or ref_value.
+__global__ void power_to_db_kernel(const float* x, int64_t stride, const int* n_valid, const float* ref_dev,
+                                   float ref_value, float amin, float top_db, const float* max_dev,
+                                   float* out) {
+    const int b = blockIdx.y;
+    const int64_t len = n_valid[b];
+    const float ref = ref_dev ? ref_dev[b] : ref_value;
+    const float ref_db = 10.0f * log10f(fmaxf(amin, ref));
+    // the largest output is that of the largest input
+    const float floor_db = 10.0f * log10f(fmaxf(amin, max_dev[b])) - ref_db - top_db;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 10.0f * log10f(fmaxf(amin, x[b * stride + i])) - ref_db;
+        if (top_db >= 0.f) v = fmaxf(v, floor_db);
+        out[b * stride + i] = v;
+    }
+}
+
 // x -> x^(1/power), in place (librosa.feature.inverse.mel_to_stft's last step)
 __global__ void root_kernel(float* x, int64_t n, float inv_power) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -403,6 +445,7 @@ struct glv_plan {
     void (*launch_init)(const ElemArgs&, const float*, const cf*, uint64_t, float, float*, cf*,
                         hipStream_t) = nullptr;
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
+    void (*launch_power)(const ElemArgs&, const cf*, float*, hipStream_t) = nullptr;
 };
 
 namespace {
@@ -465,8 +508,15 @@ void launch_convert_t(bool to_native, const ElemArgs& ea, const cf* src, float i
                            ea, src, inv_n, dst);
 }
 
+template <int A>
+void launch_power_t(const ElemArgs& ea, const cf* spec, float* power, hipStream_t st) {
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * ea.L.P;
+    hipLaunchKernelGGL((spec_power_kernel<A>), dim3(grid_for(total, 256)), dim3(256), 0, st, ea, spec, power);
+}
+
 template <int A, int HB>
 void bind_launchers(glv_plan* p) {
+    p->launch_power = &launch_power_t<A>;
     p->launch_engine = &launch_engine_t<A, HB>;
     p->engine_blocks_per_cu = &engine_blocks_per_cu_t<A, HB>;
     p->launch_init = &launch_init_t<A>;
@@ -1204,6 +1254,56 @@ extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const
     set_io(p, a, 0, 1);
     HIP_TRY(p->launch_engine(MODE_STFT, false, a, engine_grid(p), st));
     p->launch_convert(false, ea, p->d_spec, 1.0f, reinterpret_cast<cf*>(D_dev), st);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+
+extern "C" int glv_melspectrogram(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+                                  int batch, int frames_stride, float* mel_dev, void* stream) {
+    if (!p || !y_dev || !mel_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (!p->have_basis) return fail(GLV_ERR_STATE, "glv_plan_set_mel_basis has not been called");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    if (rc != GLV_OK) return rc;
+    int max_t = 0;
+    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
+    const int64_t max_len = (int64_t)p->hop * (max_t - 1);
+    if (y_stride < max_len) return fail(GLV_ERR_INVALID, "y_stride shorter than hop*(n_frames-1)");
+    const ElemArgs ea = elem_args(p, batch, frames_stride);
+    hipLaunchKernelGGL(pad_signal_kernel, dim3(grid_for(std::max<int64_t>(max_len, 1), 256), batch),
+                       dim3(256), 0, st, ea, y_dev, y_stride, p->d_ym[0]);
+    IterArgs a = iter_args(p, frames_stride);
+    a.raw_in = 1;
+    set_io(p, a, 0, 1);
+    HIP_TRY(p->launch_engine(MODE_STFT, false, a, engine_grid(p), st));
+    // |D|^2 in natural order (the S workspace is idle here), then mel = power @ basis^T
+    p->launch_power(ea, p->d_spec, p->d_S, st);
+    const int64_t rows = (int64_t)batch * frames_stride;
+    const dim3 grid((p->n_mels + 63) / 64, (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_STORE>), grid, dim3(256), 0, st, p->d_S, p->d_basis, rows, p->F,
+                       p->n_mels, 0.f, 0.f, 0.f, (const float*)nullptr, mel_dev);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
+}
+
+extern "C" int glv_power_to_db(glv_plan* p, const float* x_dev, const int* n_valid_host, int batch,
+                               int64_t stride, int ref_is_max, float ref_value, float amin, float top_db,
+                               float* out_dev, void* stream) {
+    if (!p || !x_dev || !out_dev || !n_valid_host) return fail(GLV_ERR_INVALID, "null argument");
+    if (!(amin > 0.f)) return fail(GLV_ERR_INVALID, "amin must be strictly positive");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    // per-row maximum (power is non-negative): the reference level and/or the top_db floor
+    int rc = glv_peak_reduce(p, x_dev, n_valid_host, batch, stride, reinterpret_cast<float*>(p->d_peak), stream);
+    if (rc != GLV_OK) return rc;
+    int64_t max_len = 1;
+    for (int b = 0; b < batch; ++b) max_len = std::max<int64_t>(max_len, n_valid_host[b]);
+    const dim3 grid(std::min<unsigned>(grid_for(max_len, 256 * 4), 256), batch);
+    const float* maxes = reinterpret_cast<const float*>(p->d_peak);
+    hipLaunchKernelGGL(power_to_db_kernel, grid, dim3(256), 0, st, x_dev, stride, p->d_nsamples,
+                       ref_is_max ? maxes : (const float*)nullptr, ref_value, amin, top_db, maxes, out_dev);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

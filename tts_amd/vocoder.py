@@ -22,7 +22,8 @@ import torch
 from . import _lib
 from .filters import inverse_mel_basis, mel_basis_and_step
 
-__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch", "mel_to_audio"]
+__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch", "mel_to_audio",
+           "audio_to_mel_db"]
 
 
 def _stream_ptr(device):
@@ -261,6 +262,38 @@ class GriffinLimPlan:
         _lib.check(self.lib.glv_shard_end(self._handle, _ptr(y), _stream_ptr(self.device)))
         return y[: int(n_count.value)], int(n_begin.value)
 
+    def melspectrogram(self, y, n_frames=None):
+        """(B, hop*(T-1)) -> (B, T, n_mels) mel power: librosa.feature.melspectrogram
+        (reference acoustic/dataset.py:75-83); set_mel_basis first."""
+        self._check(y, (y.shape[-1],), "y")
+        if self._basis_key is None:
+            raise RuntimeError("set_mel_basis(sr, fmin, fmax) first")
+        b, stride = y.shape
+        t = stride // self.hop_length + 1
+        nf, nf_ptr = self._frames(n_frames, b, t)
+        out = torch.zeros((b, t, self.n_mels), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_melspectrogram(self._handle, _ptr(y), stride, nf_ptr, b, t, _ptr(out),
+                                               _stream_ptr(self.device)))
+        return out
+
+    def power_to_db(self, x, n_valid=None, ref="max", amin=1e-10, top_db=80.0):
+        """librosa.power_to_db row by row on a (B, ...) tensor; ref="max" is ref=np.max
+        (reference acoustic/dataset.py:84), a number is used as is; top_db=None disables
+        the floor.  n_valid[b] = leading values of the flattened row b that count."""
+        b = x.shape[0]
+        flat = x.reshape(b, -1)
+        self._check(flat, (flat.shape[1],), "x")
+        _, ptr = _int_array([flat.shape[1]] * b if n_valid is None else n_valid)
+        out = torch.zeros_like(flat)
+        ref_is_max = isinstance(ref, str)
+        if ref_is_max and ref != "max":
+            raise ValueError('ref must be "max" or a number')
+        _lib.check(self.lib.glv_power_to_db(self._handle, _ptr(flat), ptr, b, flat.shape[1], int(ref_is_max),
+                                            0.0 if ref_is_max else float(ref), float(amin),
+                                            -1.0 if top_db is None else float(top_db), _ptr(out),
+                                            _stream_ptr(self.device)))
+        return out.reshape(x.shape)
+
     def stft(self, y, n_frames=None):
         """(B, hop*(T-1)) -> (B, T, F, 2); librosa.stft(center=True, pad_mode='constant')."""
         self._check(y, (y.shape[-1],), "y")
@@ -436,3 +469,25 @@ def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_len
         seed, phase0 = 0, _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
     y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)[0]
     return y if return_tensor else y.cpu().numpy()
+
+
+def audio_to_mel_db(y, sr=22050, n_fft=2048, hop_length=256, win_length=2048, n_mels=80, fmax=8000, *,
+                    device=None, return_tensor=False):
+    """The reference's mel extraction (acoustic/dataset.py:75-84):
+    ``librosa.power_to_db(librosa.feature.melspectrogram(y=y, sr=sr, n_mels=80, fmax=8000,
+    n_fft=2048, hop_length=256, win_length=2048), ref=np.max).T`` -> (T, n_mels) dB in
+    [-80, 0].  The signal is cut to a whole number of hops (T = 1 + len(y) // hop_length
+    frames, as librosa frames it; the up to hop_length-1 trailing samples librosa's last
+    frames would still see are dropped)."""
+    sig = y.detach() if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+    if sig.dim() != 1:
+        raise ValueError("y must be 1-D")
+    frames = 1 + sig.shape[0] // hop_length
+    if frames < 2:
+        raise ValueError("signal shorter than one hop")
+    plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
+    plan.set_mel_basis(sr, 0.0, fmax)
+    sig = sig[: hop_length * (frames - 1)].to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
+    mel = plan.melspectrogram(sig)
+    db = plan.power_to_db(mel)[0]
+    return db if return_tensor else db.cpu().numpy()
