@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--n-fft", type=int, default=N_FFT, help="n_fft = win_length (default workload: 1024)")
     ap.add_argument("--frames-per-run", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--recompute", type=int, default=-1,
+                    help="1/0: force the iteration variant that recomputes the previous spectrum (default: library choice)")
+    ap.add_argument("--alias-utts", action="store_true",
+                    help="measurement aid: all utterances share one utterance's memory (cache-resident loop)")
     ap.add_argument("--traffic-only", action="store_true",
                     help="measurement aid: iteration kernels move their data but compute nothing")
     ap.add_argument("--cpu-utts", type=int, default=32)
@@ -133,6 +137,10 @@ def main():
         plan.set_option("use_graph", 0)
     if args.traffic_only:
         plan.set_option("traffic_only", 1)
+    if args.alias_utts:
+        plan.set_option("alias_utts", 1)
+    if args.recompute >= 0:
+        plan.set_option("recompute", args.recompute)
     mel = torch.from_numpy(mel_host).to(device)
     n_samples = [HOP * (t - 1) for t in frames_list]
     out = torch.empty((args.batch, HOP * (t_max - 1)), dtype=torch.float32, device=device)
@@ -165,7 +173,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert args.traffic_only or bool(torch.isfinite(out).all()), "non-finite audio"
+    assert args.traffic_only or args.alias_utts or bool(torch.isfinite(out).all()), "non-finite audio"
 
     if rank == 0:
         audio_s = sum(n_samples) / SR

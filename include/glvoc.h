@@ -198,6 +198,12 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
  *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
  *                        "timing" (0/1: bracket the iteration loop with hipEvents),
+ *                        "recompute" (0/1: iterate without the spectrum state in memory - the
+ *                        momentum term's previous spectrum is recomputed from the previous
+ *                        signal; one more forward FFT per frame, 2.4x fewer bytes),
+ *                        "alias_utts" (0/1: measurement aid - every utterance of the batch uses the first
+ *                        one's state, so the loop runs out of cache: compute-only time; output is
+ *                        garbage),
  *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue
  *                        their loads and stores but skip the arithmetic; output is garbage).
  *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration

@@ -28,14 +28,31 @@ void emu_launch(const IterArgs& a) {
     for (int ri = 0; ri < a.n_runs; ++ri) {
         const RunDesc run = a.runs[ri];
         for (int l = 0; l < 64; ++l) e[l].init(a, a.tables, l, run);
+        constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
+        constexpr int kRcArg = MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0);
         if (MODE != MODE_ISTFT)
             for (int l = 0; l < 64; ++l) {
                 e[l].preload(a);
                 e[l].prefetch_block(a, run.t_begin);
             }
+        if (MODE == MODE_ITER_RC)
+            for (int l = 0; l < 64; ++l) {
+                e[l].preload_prev(a);
+                e[l].prefetch_block_prev(a, run.t_begin);
+            }
         if (MODE == MODE_ITER)
             for (int l = 0; l < 64; ++l) e[l].prefetch_spec(a, run.t_begin);
+        if (kRc)
+            for (int l = 0; l < 64; ++l) e[l].prefetch_s(a, run.t_begin);
         for (int t = run.t_begin; t < run.t_end; ++t) {
+            if (MODE == MODE_ITER_RC) {
+                for (int l = 0; l < 64; ++l) e[l].ph0_prev(a, t, b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph3_prev(b0.data());
+            }
             if (MODE != MODE_ISTFT) {
                 for (int l = 0; l < 64; ++l) e[l].ph0(a, t, b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
@@ -46,7 +63,7 @@ void emu_launch(const IterArgs& a) {
                     for (int l = 0; l < 64; ++l) e[l].ph3_stft(a, t, b0.data());
                     continue;
                 }
-                for (int l = 0; l < 64; ++l) e[l].template ph3_update<SC>(a, t, b0.data());
+                for (int l = 0; l < 64; ++l) e[l].template ph3_update<SC, kRcArg>(a, t, b0.data());
             } else {
                 for (int l = 0; l < 64; ++l) e[l].ph3_load(a, t);
             }
@@ -83,7 +100,7 @@ struct Emu {
     std::vector<RunDesc> runs;
     std::vector<unsigned char> flags;
     std::vector<cf> spec;
-    std::vector<float> S_native, ym[2], yt[2], sc_partial, zeros, trash;
+    std::vector<float> S_native, ym[3], yt[3], sc_partial, zeros, trash;
     std::vector<int> nf;
     int batch, Ts, blocks;
     LayoutArgs L;
@@ -98,7 +115,7 @@ struct Emu {
         flags = build_tail_flags(runs, batch, blocks, R);
         spec.assign((size_t)batch * Ts * P, cf{0, 0});
         S_native.assign((size_t)batch * Ts * (P + 4), 0.f);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             ym[i].assign((size_t)batch * blocks * H, 0.f);
             yt[i].assign((size_t)batch * blocks * H, 0.f);
         }
@@ -139,7 +156,7 @@ struct Emu {
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
-                   float* y, int64_t y_stride, float* sc) {
+                   float* y, int64_t y_stride, float* sc, bool recompute) {
         for (int b = 0; b < batch; ++b)
             for (int t = 0; t < nf[b]; ++t)
                 for (int q = 0; q < P; ++q)
@@ -153,12 +170,27 @@ struct Emu {
         for (int k = 0; k < n_iter; ++k) {
             a.has_prev = k > 0;
             a.sc_partial = sc ? sc_partial.data() : nullptr;
-            io(cur, cur ^ 1);
-            if (sc)
-                emu_launch<A, HB, MODE_ITER, true>(a);
-            else
-                emu_launch<A, HB, MODE_ITER, false>(a);
-            cur ^= 1;
+            if (recompute) {
+                const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
+                io(cur, out);
+                a.y_prev = ym[prev].data();
+                a.y_prev_tail = yt[prev].data();
+                if (k == 0) {
+                    if (sc) emu_launch<A, HB, MODE_ITER_RC_FIRST, true>(a);
+                    else emu_launch<A, HB, MODE_ITER_RC_FIRST, false>(a);
+                } else {
+                    if (sc) emu_launch<A, HB, MODE_ITER_RC, true>(a);
+                    else emu_launch<A, HB, MODE_ITER_RC, false>(a);
+                }
+                cur = out;
+            } else {
+                io(cur, cur ^ 1);
+                if (sc)
+                    emu_launch<A, HB, MODE_ITER, true>(a);
+                else
+                    emu_launch<A, HB, MODE_ITER, false>(a);
+                cur ^= 1;
+            }
             if (sc) {
                 for (int b = 0; b < batch; ++b) {
                     double num = 0, den = 0;
@@ -223,11 +255,11 @@ extern "C" {
 
 int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const float* phase0,
                    uint64_t seed, const int* n_frames, int batch, int frames_stride, int n_iter,
-                   float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc) {
+                   float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc, int recompute) {
     return dispatch(n_fft, hop, [&](auto* tag) {
         using E = std::remove_pointer_t<decltype(tag)>;
         E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
-        return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
+        return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, recompute != 0);
     });
 }
 

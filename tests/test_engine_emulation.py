@@ -20,7 +20,8 @@ def P(a):
     return a.ctypes.data_as(fp)
 
 
-def emu_griffinlim(emu, s_btf, ph_btf2, lens, n_fft, hop, win, n_iter, fpr, momentum=0.99, want_sc=True):
+def emu_griffinlim(emu, s_btf, ph_btf2, lens, n_fft, hop, win, n_iter, fpr, momentum=0.99, want_sc=True,
+                   recompute=0):
     b, t, _ = s_btf.shape
     stride = hop * (t - 1)
     y = np.zeros((b, stride), np.float32)
@@ -28,7 +29,7 @@ def emu_griffinlim(emu, s_btf, ph_btf2, lens, n_fft, hop, win, n_iter, fpr, mome
     nf = np.asarray(lens, np.int32)
     rc = emu.emu_griffinlim(n_fft, hop, win, P(s_btf), P(ph_btf2), ctypes.c_uint64(0), nf.ctypes.data_as(ip),
                             b, t, n_iter, ctypes.c_float(momentum), fpr, P(y), ctypes.c_int64(stride),
-                            P(sc) if (want_sc and n_iter > 0) else None)
+                            P(sc) if (want_sc and n_iter > 0) else None, recompute)
     assert rc == 0
     return y, sc[:, :n_iter]
 
@@ -128,3 +129,21 @@ def test_fixture_drift_stays_at_the_fp32_noise_floor(emu, lj001):
     y, sc = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [430], 1024, 256, 1024, 16, 14)
     assert rel_l2(y[0], snaps[16]) < 2e-4
     assert np.max(np.abs(sc[0] - sc_ref) / sc_ref) < 1e-5
+
+
+@pytest.mark.parametrize("n_fft,hop,win,frames,fpr", [(1024, 256, 1024, 23, 7), (2048, 256, 2048, 26, 9),
+                                                      (1024, 512, 1024, 12, 3), (1024, 128, 1024, 30, 9)])
+def test_recompute_mode_is_the_same_iteration(emu, n_fft, hop, win, frames, fpr):
+    """The variant that recomputes the previous spectrum from the previous signal instead of
+    keeping it in memory performs the same arithmetic: results agree with the stored-spectrum
+    variant to the last bits and with the oracle."""
+    rng = np.random.default_rng(200 + frames)
+    f = n_fft // 2 + 1
+    s = (rng.standard_normal((f, frames)) ** 2).astype(np.float32)
+    ph = np.exp(2j * np.pi * rng.random((f, frames))).astype(np.complex64)
+    y_ref, sc_ref = O.griffinlim(s, n_iter=5, hop_length=hop, win_length=win, init_phase=ph, return_sc=True)
+    y0, sc0 = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr)
+    y1, sc1 = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr, recompute=1)
+    assert rel_l2(y1[0], y0[0]) < 1e-6
+    assert rel_l2(y1[0], y_ref) < 5e-6
+    assert np.max(np.abs(sc1[0] - sc_ref) / sc_ref) < 1e-5

@@ -382,3 +382,26 @@ def test_forward_mel_extraction_and_round_trip(voc, O, lj001):
     db0, db1 = O.power_to_db(m0, ref=np.max), O.power_to_db(m1, ref=m0.max())
     loud = db0 > -40
     assert np.mean(np.abs(db1[loud] - db0[loud])) < 3.0                          # dB
+
+
+@pytest.mark.parametrize("n_fft,hop,frames", [(1024, 256, 120), (2048, 256, 96), (1024, 512, 40)])
+def test_recompute_variant_matches(voc, O, lj001, n_fft, hop, frames):
+    """The iteration variant that recomputes the momentum term's previous spectrum instead of
+    storing it: same results as the stored-state variant (to rounding) and the oracle."""
+    mel, mean, std = lj001
+    s = O.mel_invert(mel[30:30 + frames], mean, std, n_fft=n_fft)
+    ph = phasors(31, s.shape[0], frames)
+    _, sc_ref, snaps = O.griffinlim(s, n_iter=16, hop_length=hop, win_length=n_fft, init_phase=ph,
+                                    return_sc=True, snapshots=[1, 2, 3, 16])
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, 1)
+    sd, pd = dev(to_btf(s)), dev(to_btf2(ph))
+    for k in (1, 2, 3, 16):
+        plan.set_option("recompute", 0)
+        y0 = plan.griffinlim(sd, phase0=pd, n_iter=k).cpu().numpy()[0]
+        plan.set_option("recompute", 1)
+        y1, sc = plan.griffinlim(sd, phase0=pd, n_iter=k, return_sc=True)
+        y1, sc = y1.cpu().numpy()[0], sc.cpu().numpy()[0]
+        assert rel_l2(y1, y0) < 1e-4, k
+        assert rel_l2(y1, snaps[k]) < 1e-3, k
+        assert np.max(np.abs(sc - sc_ref[:k]) / sc_ref[:k]) < 1e-2
+    plan.close()

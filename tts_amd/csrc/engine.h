@@ -51,7 +51,17 @@ struct RunDesc {
 
 // MODE_TRAFFIC: the iteration kernel's loads and stores with the arithmetic removed - a
 // measurement aid that gives the memory-system ceiling of this access pattern.
-enum Mode { MODE_ITER = 0, MODE_ISTFT = 1, MODE_STFT = 2, MODE_TRAFFIC = 3 };
+// MODE_ITER_RC / MODE_ITER_RC_FIRST: the iteration without the spectrum state in HBM - the
+// previous rebuilt spectrum (the momentum term) is recomputed from the previous signal,
+// which costs one more forward FFT per frame and saves reading and writing 8P bytes.
+enum Mode {
+    MODE_ITER = 0,
+    MODE_ISTFT = 1,
+    MODE_STFT = 2,
+    MODE_TRAFFIC = 3,
+    MODE_ITER_RC = 4,
+    MODE_ITER_RC_FIRST = 5
+};
 
 struct IterArgs {
     const RunDesc* runs;
@@ -60,6 +70,8 @@ struct IterArgs {
     const float* S;           // native target magnitudes, [utt][frame][P+4] (Nyquist at [P])
     const float* y_in;        // previous overlap-add sums (or padded signal if raw_in)
     const float* y_in_tail;
+    const float* y_prev;      // the signal one iteration older than y_in (MODE_ITER_RC)
+    const float* y_prev_tail;
     float* y_out;
     float* y_out_tail;
     int64_t spec_utt_stride;  // cf units
@@ -120,6 +132,7 @@ struct Engine {
     static constexpr bool kPrefetchTp = GLV_PREFETCH_TP_ALL || (A == 1);
 
     cf raw[kSlide ? E : HB];
+    cf rawp[E];  // window over the previous signal (MODE_ITER_RC)
     cf acc[E];
     cf v[E];
     // loads issued one frame ahead of their use (software prefetch)
@@ -163,10 +176,14 @@ struct Engine {
         return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
     }
     GLV_HD void fetch_block(const IterArgs& a, int j, BlockFetch& f) const {
+        fetch_block_from(a, a.y_in, a.y_in_tail, j, f);
+    }
+    GLV_HD void fetch_block_from(const IterArgs& a, const float* y_main, const float* y_tail, int j,
+                                 BlockFetch& f) const {
         const bool valid = block_valid(j);
         const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
-        const float* pm = (valid && (a.raw_in || j < run.n_frames)) ? a.y_in + base : a.zeros;
-        const float* pt = (valid && block_has_tail(a, j)) ? a.y_in_tail + base : a.zeros;
+        const float* pm = (valid && (a.raw_in || j < run.n_frames)) ? y_main + base : a.zeros;
+        const float* pt = (valid && block_has_tail(a, j)) ? y_tail + base : a.zeros;
         const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
@@ -189,6 +206,7 @@ struct Engine {
         finish_block(a, f, out);
     }
     BlockFetch blk_n;
+    BlockFetch blkp_n;  // same, previous signal (MODE_ITER_RC)
 
     // issue the loads frame t will need (t clamped into the run: the last frame re-requests
     // its own data rather than branching): its newest signal block ...
@@ -196,10 +214,18 @@ struct Engine {
         const int tt = t < run.t_end ? t : run.t_end - 1;
         fetch_block(a, tt + R - 1, blk_n);
     }
+    GLV_HD void prefetch_block_prev(const IterArgs& a, int t) {
+        const int tt = t < run.t_end ? t : run.t_end - 1;
+        fetch_block_from(a, a.y_prev, a.y_prev_tail, tt + R - 1, blkp_n);
+    }
     // ... and its previous spectrum and target magnitudes
     GLV_HD void prefetch_spec(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
         if (kPrefetchTp) load_spec(a, tt, tp_n);
+        prefetch_s(a, t);
+    }
+    GLV_HD void prefetch_s(const IterArgs& a, int t) {
+        const int tt = t < run.t_end ? t : run.t_end - 1;
         const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
@@ -223,6 +249,35 @@ struct Engine {
         if (!kSlide) return;
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) load_block(a, run.t_begin + q, &raw[q * HB]);
+    }
+    GLV_HD void preload_prev(const IterArgs& a) {
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) {
+            BlockFetch f;
+            fetch_block_from(a, a.y_prev, a.y_prev_tail, run.t_begin + q, f);
+            finish_block(a, f, &rawp[q * HB]);
+        }
+    }
+    // ---- phase 0 on the previous signal (MODE_ITER_RC): same frame, older iterate ----
+    GLV_HD void ph0_prev(const IterArgs& a, int t, cf* w) {
+        finish_block(a, blkp_n, &rawp[(R - 1) * HB]);
+        prefetch_block_prev(a, t + 1);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const cf wn = tab.win[r * 64 + lane];
+            v[r] = cf{rawp[r].x * wn.x, rawp[r].y * wn.y};
+        }
+#pragma unroll
+        for (int r = 0; r + HB < E; ++r) rawp[r] = rawp[r + HB];
+        F::fwd_a(v, tab, w, lane);
+    }
+    // finishes the previous signal's frame: its spectrum is the momentum term's tprev
+    GLV_HD void ph3_prev(const cf* r) {
+        cf m[E];
+        F::mirror_load(m, r, mbase);
+        F::split_fwd(v, m, tab, lane);
+#pragma unroll
+        for (int reg = 0; reg < E; ++reg) tp_n[reg] = v[reg];
     }
 
     // ---- phase 0: newest block, window, first DFT pass ----
@@ -287,15 +342,21 @@ struct Engine {
     // ---- phase 3 (iteration): rebuilt spectrum, momentum phase update ----
     // librosa.griffinlim loop body after the stft: angles = rebuilt - c*tprev;
     // angles /= |angles| + tiny; angles *= S; tprev = rebuilt.
-    template <bool SC>
+    // RC = 0: tprev lives in `spec` (read, then overwritten with rebuilt); 1: tprev was just
+    // recomputed into tp_n and nothing is stored; 2: first iteration of that scheme (no tprev).
+    template <bool SC, int RC = 0>
     GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
-        if (!kPrefetchTp) load_spec(a, t, tp_n);
+        if (RC == 0 && !kPrefetchTp) load_spec(a, t, tp_n);
         // first iteration: no momentum term (tp_n then holds the initial angles, times zero)
-        const float cmom = a.has_prev ? a.cmom : 0.0f;
+        const float cmom = (RC == 2 || (RC == 0 && !a.has_prev)) ? 0.0f : a.cmom;
+        if (RC == 2) {
+#pragma unroll
+            for (int reg = 0; reg < E; ++reg) tp_n[reg] = cf{0.f, 0.f};
+        }
         F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
-        store_spec(a, t);
+        if (RC == 0) store_spec(a, t);
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) {
             const cf x = v[reg];
@@ -316,7 +377,10 @@ struct Engine {
             const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
             v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
         }
-        prefetch_spec(a, t + 1);
+        if (RC == 0)
+            prefetch_spec(a, t + 1);
+        else
+            prefetch_s(a, t + 1);
     }
     // ---- MODE_TRAFFIC: one frame's memory operations, nothing else ----
     GLV_HD void traffic_frame(const IterArgs& a, int t) {

@@ -94,15 +94,36 @@ gl_engine_kernel(IterArgs a) {
     rd.n_frames = __builtin_amdgcn_readfirstlane(rd.n_frames);
     Eng e;
     e.init(a, tables, lane, rd);
+    constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
     if (MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
     }
+    if (MODE == MODE_ITER_RC) {
+        e.preload_prev(a);
+        e.prefetch_block_prev(a, e.run.t_begin);
+    }
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
+    if (kRc) e.prefetch_s(a, e.run.t_begin);
     for (int t = e.run.t_begin; t < e.run.t_end; ++t) {
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
             continue;
+        }
+        if (MODE == MODE_ITER_RC) {
+            // forward transform of the same frame of the previous signal -> tprev
+            e.ph0_prev(a, t, xb);
+            wave_sync();
+            e.ph1_read(xb);
+            wave_sync();
+            e.ph1_write(xb);
+            wave_sync();
+            e.ph2_read(xb);
+            wave_sync();
+            e.ph2_write(xb);
+            wave_sync();
+            e.ph3_prev(xb);
+            wave_sync();
         }
         if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
@@ -120,7 +141,7 @@ gl_engine_kernel(IterArgs a) {
                 wave_sync();
                 continue;
             }
-            e.template ph3_update<SC>(a, t, xb);
+            e.template ph3_update<SC, (MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0))>(a, t, xb);
         } else {
             e.ph3_load(a, t);
         }
@@ -387,6 +408,8 @@ struct glv_plan {
     int use_graph = 1;
     int timing = 0;
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
+    int recompute = 0;     // iterate without the spectrum state in HBM (MODE_ITER_RC)
+    int alias_utts = 0;    // measurement aid: all utterances share one utterance's memory
     // device tables
     cf* d_tables = nullptr;
     float* d_w2 = nullptr;
@@ -404,8 +427,8 @@ struct glv_plan {
     // device workspace
     cf* d_spec = nullptr;
     float* d_S = nullptr;
-    float* d_ym[2] = {nullptr, nullptr};
-    float* d_yt[2] = {nullptr, nullptr};
+    float* d_ym[3] = {nullptr, nullptr, nullptr};  // overlap-add generations (2 used unless "recompute")
+    float* d_yt[3] = {nullptr, nullptr, nullptr};
     RunDesc* d_runs = nullptr;
     unsigned char* d_flags = nullptr;
     int* d_nframes = nullptr;
@@ -460,6 +483,16 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_RC) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_RC, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_RC, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_RC_FIRST) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_RC_FIRST, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_RC_FIRST, false>), g, b, lds, st, a);
     } else if (mode == MODE_TRAFFIC) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT) {
@@ -538,7 +571,7 @@ void plan_free(glv_plan* p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     void* dev[] = {p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
-                   p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_runs,    p->d_flags,
+                   p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
         if (q) (void)hipFree(q);
@@ -566,6 +599,7 @@ IterArgs iter_args(const glv_plan* p, int frames_stride) {
     a.spec_utt_stride = (int64_t)frames_stride * p->P;
     a.s_utt_stride = (int64_t)frames_stride * (p->P + 4);
     a.y_utt_stride = (int64_t)p->blocks * p->hop;
+    if (p->alias_utts) a.spec_utt_stride = a.s_utt_stride = a.y_utt_stride = 0;
     a.w2 = p->d_w2;
     a.iwss = p->d_iwss;
     a.iwss_head = p->d_iwss_head;
@@ -747,7 +781,7 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(dmalloc(p, &p->d_resid, frames * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_spec, frames * p->P));
     PLAN_TRY(dmalloc(p, &p->d_S, frames * (p->P + 4)));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         PLAN_TRY(dmalloc(p, &p->d_ym[i], ylen));
         PLAN_TRY(dmalloc(p, &p->d_yt[i], ylen));
     }
@@ -794,6 +828,18 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->use_graph = value != 0;
     } else if (!strcmp(name, "timing")) {
         p->timing = value != 0;
+    } else if (!strcmp(name, "alias_utts")) {
+        p->alias_utts = value != 0;
+        if (p->graph_exec) {
+            (void)hipGraphExecDestroy(p->graph_exec);
+            p->graph_exec = nullptr;
+        }
+    } else if (!strcmp(name, "recompute")) {
+        p->recompute = value != 0;
+        if (p->graph_exec) {
+            (void)hipGraphExecDestroy(p->graph_exec);
+            p->graph_exec = nullptr;
+        }
     } else if (!strcmp(name, "traffic_only")) {
         p->traffic_only = value != 0;
         if (p->graph_exec) {
@@ -884,18 +930,31 @@ extern "C" int glv_mel_invert_nnls(glv_plan* p, const float* mel_dev, int batch,
 
 namespace {
 
-// enqueues the n_iter iteration kernels (and nothing else) on st
-int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool with_sc, hipStream_t st) {
+// enqueues the n_iter iteration kernels (and nothing else) on st; *last receives the index
+// of the overlap-add generation the final iteration wrote
+int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool with_sc, hipStream_t st,
+                 int* last) {
     IterArgs a = iter_args(p, frames_stride);
     a.cmom = cmom;
-    int cur = 0;  // the iSTFT of the initial angles wrote buffer 0
+    int cur = 0;  // the iSTFT of the initial angles wrote generation 0
     for (int k = 0; k < n_iter; ++k) {
         a.has_prev = k > 0;
         a.sc_partial = with_sc ? p->d_sc_partial + (size_t)k * p->n_runs * 2 : nullptr;
-        set_io(p, a, cur, cur ^ 1);
-        HIP_TRY(p->launch_engine(p->traffic_only ? MODE_TRAFFIC : MODE_ITER, with_sc, a, engine_grid(p), st));
-        cur ^= 1;
+        if (p->recompute && !p->traffic_only) {
+            // three generations rotate: read `cur` (and the one before it), write the next
+            const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
+            set_io(p, a, cur, out);
+            a.y_prev = p->d_ym[prev];
+            a.y_prev_tail = p->d_yt[prev];
+            HIP_TRY(p->launch_engine(k == 0 ? MODE_ITER_RC_FIRST : MODE_ITER_RC, with_sc, a, engine_grid(p), st));
+            cur = out;
+        } else {
+            set_io(p, a, cur, cur ^ 1);
+            HIP_TRY(p->launch_engine(p->traffic_only ? MODE_TRAFFIC : MODE_ITER, with_sc, a, engine_grid(p), st));
+            cur ^= 1;
+        }
     }
+    if (last) *last = cur;
     return GLV_OK;
 }
 
@@ -958,7 +1017,7 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
                 hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
                 int lrc = GLV_OK;
                 if (e == hipSuccess) {
-                    lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap);
+                    lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap, nullptr);
                     e = hipStreamEndCapture(cap, &graph);
                 }
                 if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
@@ -973,7 +1032,7 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
             }
             HIP_TRY(hipGraphLaunch(p->graph_exec, st));
         } else {
-            rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st);
+            rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st, nullptr);
             if (rc != GLV_OK) return rc;
         }
     }
@@ -981,7 +1040,7 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
         HIP_TRY(hipEventRecord(p->ev1, st));
         p->ev_valid = true;
     }
-    const int last = n_iter & 1;
+    const int last = (p->recompute && !p->traffic_only) ? n_iter % 3 : (n_iter & 1);
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
                        p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0);
