@@ -50,8 +50,9 @@ int glv_version(void);
  * Creates the per-shape state: window / twiddle / window-sum-square tables and
  * the device workspace of the iteration loop.  Stands in for the keyword
  * defaults of the reference signature (vocoder/mel_audio.py:112).
- * Supported: n_fft in {1024, 2048}; hop in {128, 256, 512} with
- * hop <= n_fft/2; win_length <= n_fft (periodic Hann, centred zero padding).
+ * Supported: n_fft in {1024, 2048}; hop in {n_fft/8, n_fft/4, n_fft/2}
+ * (128, 256, 512 for n_fft 1024; 256, 512, 1024 for n_fft 2048);
+ * win_length <= n_fft (periodic Hann, centred zero padding).
  */
 int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_length, int n_mels,
                     int max_frames, int max_batch, int device);

@@ -94,7 +94,7 @@ struct Shape {
 template <int A, int HB>
 struct Emu {
     using G = Geo<A>;
-    static constexpr int R = G::E / HB, H = 128 * HB, P = G::P, F = G::P + 1;
+    static constexpr int R = 8 / HB, H = G::ROW * HB, P = G::P, F = G::P + 1;
 
     HostTables tab;
     std::vector<RunDesc> runs;
@@ -238,8 +238,9 @@ struct Emu {
 
 template <typename Fn>
 int dispatch(int n_fft, int hop, Fn&& fn) {
-    const int hb = hop / 128;
-    if (hop % 128 != 0) return -2;
+    const int row = n_fft / 8;  // samples per row of the engine's time layout
+    if (n_fft <= 0 || hop % row != 0) return -2;
+    const int hb = hop / row;
     if (n_fft == 1024 && hb == 1) return fn((Emu<1, 1>*)nullptr);
     if (n_fft == 1024 && hb == 2) return fn((Emu<1, 2>*)nullptr);
     if (n_fft == 1024 && hb == 4) return fn((Emu<1, 4>*)nullptr);

@@ -36,7 +36,7 @@ def emu_griffinlim(emu, s_btf, ph_btf2, lens, n_fft, hop, win, n_iter, fpr, mome
 
 SHAPES = [(1024, 256, 1024, 23, 7), (1024, 256, 1024, 23, 100), (2048, 256, 2048, 26, 9),
           (2048, 512, 2048, 17, 5), (1024, 512, 1024, 9, 3), (1024, 128, 1024, 30, 9),
-          (2048, 128, 2048, 40, 16), (1024, 256, 800, 15, 4), (1024, 256, 1024, 2, 8),
+          (2048, 1024, 2048, 12, 4), (1024, 256, 800, 15, 4), (1024, 256, 1024, 2, 8),
           (1024, 256, 1024, 5, 2)]
 
 

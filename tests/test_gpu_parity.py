@@ -38,7 +38,8 @@ def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
-SHAPES = [(1024, 256, 1024), (2048, 256, 2048), (2048, 512, 2048), (1024, 128, 1024), (1024, 512, 800)]
+SHAPES = [(1024, 256, 1024), (2048, 256, 2048), (2048, 512, 2048), (1024, 128, 1024), (1024, 512, 800),
+          (2048, 1024, 2048)]
 
 
 @pytest.mark.parametrize("n_fft,hop,win", SHAPES)

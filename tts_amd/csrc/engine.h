@@ -6,8 +6,9 @@
 // Overlap-add without atomics or barriers: consecutive frames overlap by
 // N - H samples, so the wave keeps the N-sample running sum in registers
 // (`acc`), adds each windowed frame, emits the H oldest samples (now complete)
-// and shifts by H.  H = 128*HB samples is exactly HB registers per lane, so the
-// shift is register renaming.  The same trick slides the STFT input (`raw`).
+// and shifts by H.  H = HB rows of 128*A samples (see wave_fft.h) is exactly HB registers
+// of every sub-sequence per lane, so the shift is register renaming.  The same trick
+// slides the STFT input (`raw`).
 //
 // Run boundaries: the first R-1 blocks a run emits lack the contributions of
 // the previous run's last frames ("heads"); the R-1 blocks left in `acc`
@@ -27,17 +28,22 @@
 
 #include "wave_fft.h"
 
-// Build-time tuning switches for the 16-values-per-lane engine (n_fft 2048), whose
-// register budget is tight: 1 = as for n_fft 1024 (slide the STFT input in registers /
-// fetch the previous spectrum a frame ahead).  Measured on MI355X at 64 x 865 frames, us
-// per iteration: one wave per SIMD with both on 362; two waves per SIMD (launch bound 2,
-// a few registers spilled) with both on 372, without sliding 367, without the spectrum
-// prefetch 343 - the default.
-#ifndef GLV_SLIDE_ALL
-#define GLV_SLIDE_ALL 1
-#endif
+// Build-time tuning switch: fetch the previous spectrum a whole frame ahead of its use
+// (E more live registers) for n_fft 2048 as well, or only on demand.
 #ifndef GLV_PREFETCH_TP_ALL
-#define GLV_PREFETCH_TP_ALL 0
+#define GLV_PREFETCH_TP_ALL 1
+#endif
+// Registers of the split / phase-update step handled between two scheduling fences
+// (n_fft 2048 only): bounds how many mirror partners and previous-spectrum values are live.
+#ifndef GLV_SPLIT_CHUNK
+#define GLV_SPLIT_CHUNK 8
+#endif
+// Keeps the compiler from moving instructions across this point (it would otherwise hoist
+// every load of a phase to its top and hold all results in registers at once).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GLV_SCHED_FENCE() ((void)0)
 #endif
 namespace glv {
 
@@ -84,7 +90,7 @@ struct IterArgs {
     const float* iwss_small;  // [R-1][2R][H]: utterances shorter than R-1 frames (both sides missing)
     const float* zeros;       // H zero floats: source of blocks that do not exist
     float* trash;             // H floats nobody reads: sink of blocks that do not exist
-    const cf* tables;         // twA | twB | twP | win
+    const cf* tables;         // twA | twB | twC | twP | win
     float* sc_partial;        // [run][2] (numerator, denominator) or null
     float cmom;               // momentum / (1 + momentum)
     float inv_n;              // 1 / n_fft
@@ -121,17 +127,16 @@ struct Engine {
     using G = Geo<A>;
     using F = WaveFft<A>;
     static constexpr int E = G::E, P = G::P, N = G::N;
-    static constexpr int H = 128 * HB;  // hop
-    static constexpr int R = E / HB;    // frames covering one sample
+    static constexpr int ROW = G::ROW;   // samples per row
+    static constexpr int H = ROW * HB;   // hop
+    static constexpr int R = 8 / HB;     // frames covering one sample
+    static constexpr int HV = HB * A;    // registers per hop
+    static constexpr int CH = (A == 1) ? E : GLV_SPLIT_CHUNK;  // registers per split chunk
     static constexpr float kTiny = 1.17549435e-38f;
-    // The STFT input of consecutive frames overlaps by N - H samples: the window slides in
-    // registers and only the newest block is loaded per frame (kSlide), or all R blocks
-    // are re-read every frame (L2 hits) to save E registers.
-    static constexpr bool kSlide = GLV_SLIDE_ALL || (A == 1);
     // The previous spectrum is fetched a frame ahead (E more live registers) or on demand.
     static constexpr bool kPrefetchTp = GLV_PREFETCH_TP_ALL || (A == 1);
 
-    cf raw[kSlide ? E : HB];
+    cf raw[E];   // the window slides in registers: only the newest block is loaded per frame
     cf rawp[E];  // window over the previous signal (MODE_ITER_RC)
     cf acc[E];
     cf v[E];
@@ -139,7 +144,7 @@ struct Engine {
     cf tp_n[E];
     float s_n[E];
     float s_nyq_n;
-    int mbase[A];
+    int mbase;
     int lane;
     RunDesc run;
     float sc_num, sc_den;
@@ -150,10 +155,10 @@ struct Engine {
         run = r;
         tab.twA = tables;
         tab.twB = tab.twA + G::TW_A;
-        tab.twP = tab.twB + G::TW_B;
+        tab.twC = tab.twB + G::TW_B;
+        tab.twP = tab.twC + G::TW_C;
         tab.win = tab.twP + G::TW_P;
-#pragma unroll
-        for (int k0a = 0; k0a < A; ++k0a) mbase[k0a] = G::mirror_base(k0a, lane);
+        mbase = G::mirror_base(lane);
 #pragma unroll
         for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
         sc_num = 0.f;
@@ -167,10 +172,20 @@ struct Engine {
     // operations per frame is constant and the compiler can count them (s_waitcnt vmcnt(N))
     // instead of draining the queue.
     struct BlockFetch {
-        cf main[HB];
-        cf tail[HB];
-        cf w[HB];
+        cf main[HV];
+        cf tail[HV];
+        cf w[HV];
     };
+    // a lane's share of row i of a block: 2A contiguous floats -> one register per sub-sequence
+    GLV_HD void load_row(const float* p, int i, cf* dst) const {
+        if (A == 1) {
+            dst[i] = *reinterpret_cast<const cf*>(p + ROW * i + 2 * lane);
+        } else {
+            const f4 q = *reinterpret_cast<const f4*>(p + ROW * i + 4 * lane);
+            dst[i] = cf{q.x, q.y};
+            dst[i + HB * (A - 1)] = cf{q.z, q.w};
+        }
+    }
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
         return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
@@ -187,23 +202,35 @@ struct Engine {
         const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
-            f.main[i] = *reinterpret_cast<const cf*>(pm + 128 * i + 2 * lane);
-            f.tail[i] = *reinterpret_cast<const cf*>(pt + 128 * i + 2 * lane);
-            f.w[i] = *reinterpret_cast<const cf*>(pw + 128 * i + 2 * lane);
+            load_row(pm, i, f.main);
+            load_row(pt, i, f.tail);
+            load_row(pw, i, f.w);
         }
     }
-    GLV_HD void finish_block(const IterArgs& a, const BlockFetch& f, cf* out) const {
+    // completes a fetched block into rows row0 .. row0+HB-1 of a time-side register array
+    GLV_HD void finish_block(const IterArgs& a, const BlockFetch& f, cf (&dst)[E], int row0) const {
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const cf val = f.main[i] + f.tail[i];
-            const float wx = a.raw_in ? 1.0f : f.w[i].x, wy = a.raw_in ? 1.0f : f.w[i].y;
-            out[i] = cf{val.x * wx, val.y * wy};
-        }
+        for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int k = i + HB * s2;
+                const cf val = f.main[k] + f.tail[k];
+                const float wx = a.raw_in ? 1.0f : f.w[k].x, wy = a.raw_in ? 1.0f : f.w[k].y;
+                dst[row0 + i + 8 * s2] = cf{val.x * wx, val.y * wy};
+            }
     }
-    GLV_HD void load_block(const IterArgs& a, int j, cf* out) const {
+    GLV_HD void load_block(const IterArgs& a, const float* y_main, const float* y_tail, int j,
+                           cf (&dst)[E], int row0) const {
         BlockFetch f;
-        fetch_block(a, j, f);
-        finish_block(a, f, out);
+        fetch_block_from(a, y_main, y_tail, j, f);
+        finish_block(a, f, dst, row0);
+    }
+    // drops the oldest hop of a time-side register array
+    static GLV_HD void shift_rows(cf (&x)[E]) {
+#pragma unroll
+        for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+            for (int r = 0; r + HB < 8; ++r) x[r + 8 * s2] = x[r + HB + 8 * s2];
     }
     BlockFetch blk_n;
     BlockFetch blkp_n;  // same, previous signal (MODE_ITER_RC)
@@ -238,37 +265,39 @@ struct Engine {
         s_nyq_n = sf[P];
     }
 
-    GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf* src) const {
+    // rows row0 .. row0+HB-1 of a time-side register array -> block j
+    GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf (&src)[E], int row0) const {
         float* p = block_valid(j) ? dst + (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H : a.trash;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) *reinterpret_cast<cf*>(p + 128 * i + 2 * lane) = src[i];
+        for (int i = 0; i < HB; ++i) {
+            if (A == 1) {
+                *reinterpret_cast<cf*>(p + ROW * i + 2 * lane) = src[row0 + i];
+            } else {
+                const cf lo = src[row0 + i], hi = src[row0 + i + 8 * (A - 1)];
+                *reinterpret_cast<f4*>(p + ROW * i + 4 * lane) = f4{lo.x, lo.y, hi.x, hi.y};
+            }
+        }
     }
 
     // blocks t_begin .. t_begin+R-2 of the first frame
     GLV_HD void preload(const IterArgs& a) {
-        if (!kSlide) return;
 #pragma unroll
-        for (int q = 0; q < R - 1; ++q) load_block(a, run.t_begin + q, &raw[q * HB]);
+        for (int q = 0; q < R - 1; ++q) load_block(a, a.y_in, a.y_in_tail, run.t_begin + q, raw, q * HB);
     }
     GLV_HD void preload_prev(const IterArgs& a) {
 #pragma unroll
-        for (int q = 0; q < R - 1; ++q) {
-            BlockFetch f;
-            fetch_block_from(a, a.y_prev, a.y_prev_tail, run.t_begin + q, f);
-            finish_block(a, f, &rawp[q * HB]);
-        }
+        for (int q = 0; q < R - 1; ++q) load_block(a, a.y_prev, a.y_prev_tail, run.t_begin + q, rawp, q * HB);
     }
     // ---- phase 0 on the previous signal (MODE_ITER_RC): same frame, older iterate ----
     GLV_HD void ph0_prev(const IterArgs& a, int t, cf* w) {
-        finish_block(a, blkp_n, &rawp[(R - 1) * HB]);
+        finish_block(a, blkp_n, rawp, (R - 1) * HB);
         prefetch_block_prev(a, t + 1);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const cf wn = tab.win[r * 64 + lane];
             v[r] = cf{rawp[r].x * wn.x, rawp[r].y * wn.y};
         }
-#pragma unroll
-        for (int r = 0; r + HB < E; ++r) rawp[r] = rawp[r + HB];
+        shift_rows(rawp);
         F::fwd_a(v, tab, w, lane);
     }
     // finishes the previous signal's frame: its spectrum is the momentum term's tprev
@@ -282,34 +311,19 @@ struct Engine {
 
     // ---- phase 0: newest block, window, first DFT pass ----
     GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
-        if (kSlide) {
-            finish_block(a, blk_n, &raw[(R - 1) * HB]);
-            prefetch_block(a, t + 1);
+        finish_block(a, blk_n, raw, (R - 1) * HB);
+        prefetch_block(a, t + 1);
 #pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const cf wn = tab.win[r * 64 + lane];
-                v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
-            }
-#pragma unroll
-            for (int r = 0; r + HB < E; ++r) raw[r] = raw[r + HB];
-        } else {
-            BlockFetch f[R - 1];
-#pragma unroll
-            for (int q = 0; q < R - 1; ++q) fetch_block(a, t + q, f[q]);
-#pragma unroll
-            for (int q = 0; q < R; ++q) finish_block(a, q < R - 1 ? f[q] : blk_n, &v[q * HB]);
-            prefetch_block(a, t + 1);
-#pragma unroll
-            for (int r = 0; r < E; ++r) {
-                const cf wn = tab.win[r * 64 + lane];
-                v[r] = cf{v[r].x * wn.x, v[r].y * wn.y};
-            }
+        for (int r = 0; r < E; ++r) {
+            const cf wn = tab.win[r * 64 + lane];
+            v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
         }
+        shift_rows(raw);
         F::fwd_a(v, tab, w, lane);
     }
     GLV_HD void ph1_read(const cf* r) { F::fwd_b(v, tab, r, lane); }
     GLV_HD void ph1_write(cf* w) { F::fwd_b_store(v, w, lane); }
-    GLV_HD void ph2_read(const cf* r) { F::fwd_c(v, r, lane); }
+    GLV_HD void ph2_read(const cf* r) { F::fwd_c(v, tab, r, lane); }
     GLV_HD void ph2_write(cf* w) { F::mirror_store(v, w, lane); }
 
     GLV_HD cf* spec_frame(const IterArgs& a, int t) const {
@@ -323,16 +337,17 @@ struct Engine {
         F::split_fwd(v, m, tab, lane);
         store_spec(a, t);
     }
-    GLV_HD void store_spec(const IterArgs& a, int t) {
+    // registers q0 .. q0+nq-1 (q0, nq even) of a native frame
+    GLV_HD void store_spec(const IterArgs& a, int t, int q0 = 0, int nq = E) {
         f4* sp = reinterpret_cast<f4*>(spec_frame(a, t));
 #pragma unroll
-        for (int pq = 0; pq < E / 2; ++pq)
+        for (int pq = q0 / 2; pq < (q0 + nq) / 2; ++pq)
             sp[pq * 64 + lane] = f4{v[2 * pq].x, v[2 * pq].y, v[2 * pq + 1].x, v[2 * pq + 1].y};
     }
-    GLV_HD void load_spec(const IterArgs& a, int t, cf (&dst)[E]) const {
+    GLV_HD void load_spec(const IterArgs& a, int t, cf (&dst)[E], int q0 = 0, int nq = E) const {
         const f4* sp = reinterpret_cast<const f4*>(spec_frame(a, t));
 #pragma unroll
-        for (int pq = 0; pq < E / 2; ++pq) {
+        for (int pq = q0 / 2; pq < (q0 + nq) / 2; ++pq) {
             const f4 q = sp[pq * 64 + lane];
             dst[2 * pq] = cf{q.x, q.y};
             dst[2 * pq + 1] = cf{q.z, q.w};
@@ -346,36 +361,40 @@ struct Engine {
     // recomputed into tp_n and nothing is stored; 2: first iteration of that scheme (no tprev).
     template <bool SC, int RC = 0>
     GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
-        cf m[E];
-        F::mirror_load(m, r, mbase);
-        if (RC == 0 && !kPrefetchTp) load_spec(a, t, tp_n);
         // first iteration: no momentum term (tp_n then holds the initial angles, times zero)
         const float cmom = (RC == 2 || (RC == 0 && !a.has_prev)) ? 0.0f : a.cmom;
         if (RC == 2) {
 #pragma unroll
             for (int reg = 0; reg < E; ++reg) tp_n[reg] = cf{0.f, 0.f};
         }
-        F::split_fwd(v, m, tab, lane);  // v = rebuilt frame
-        if (RC == 0) store_spec(a, t);
 #pragma unroll
-        for (int reg = 0; reg < E; ++reg) {
-            const cf x = v[reg];
-            const bool packed = (reg == 0) && (lane == 0);
-            const float sx = s_n[reg], sy = packed ? s_nyq_n : s_n[reg];
-            if (SC) {
-                const float mag = sqrtf(x.x * x.x + x.y * x.y);
-                const float ex = (packed ? fabsf(x.x) : mag) - fabsf(sx);
-                const float ey = packed ? fabsf(x.y) - fabsf(sy) : 0.f;
-                sc_num += ex * ex + ey * ey;
-                sc_den += sx * sx + (packed ? sy * sy : 0.f);
+        for (int q0 = 0; q0 < E; q0 += CH) {
+            cf m[CH];
+            F::template mirror_load_part<CH>(m, r, mbase, q0);
+            if (RC == 0 && !kPrefetchTp) load_spec(a, t, tp_n, q0, CH);
+            F::template split_fwd_part<CH>(v, m, tab, lane, q0);  // v = rebuilt frame
+            if (RC == 0) store_spec(a, t, q0, CH);
+#pragma unroll
+            for (int reg = q0; reg < q0 + CH; ++reg) {
+                const cf x = v[reg];
+                const bool packed = (reg == 0) && (lane == 0);
+                const float sx = s_n[reg], sy = packed ? s_nyq_n : s_n[reg];
+                if (SC) {
+                    const float mag = sqrtf(x.x * x.x + x.y * x.y);
+                    const float ex = (packed ? fabsf(x.x) : mag) - fabsf(sx);
+                    const float ey = packed ? fabsf(x.y) - fabsf(sy) : 0.f;
+                    sc_num += ex * ex + ey * ey;
+                    sc_den += sx * sx + (packed ? sy * sy : 0.f);
+                }
+                const cf d = cf{x.x - cmom * tp_n[reg].x, x.y - cmom * tp_n[reg].y};
+                const float mag = sqrtf(d.x * d.x + d.y * d.y);
+                const float mx = packed ? fabsf(d.x) : mag;
+                const float my = packed ? fabsf(d.y) : mag;
+                const float ix = rcp_refined(mx + kTiny) * a.inv_n;
+                const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
+                v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
             }
-            const cf d = cf{x.x - cmom * tp_n[reg].x, x.y - cmom * tp_n[reg].y};
-            const float mag = sqrtf(d.x * d.x + d.y * d.y);
-            const float mx = packed ? fabsf(d.x) : mag;
-            const float my = packed ? fabsf(d.y) : mag;
-            const float ix = rcp_refined(mx + kTiny) * a.inv_n;
-            const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
-            v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
+            if (CH < E) GLV_SCHED_FENCE();
         }
         if (RC == 0)
             prefetch_spec(a, t + 1);
@@ -384,20 +403,21 @@ struct Engine {
     }
     // ---- MODE_TRAFFIC: one frame's memory operations, nothing else ----
     GLV_HD void traffic_frame(const IterArgs& a, int t) {
-        cf nb[HB];
-        finish_block(a, blk_n, nb);
+        cf nb[E];
+        finish_block(a, blk_n, nb, 0);
         prefetch_block(a, t + 1);
         if (!kPrefetchTp) load_spec(a, t, tp_n);
 #pragma unroll
-        for (int r = 0; r < E; ++r)
-            v[r] = cf{nb[r % HB].x + tp_n[r].x * s_n[r], nb[r % HB].y + tp_n[r].y * s_nyq_n};
+        for (int r = 0; r < E; ++r) {
+            const cf n = nb[(r % HB) + 8 * (r / 8)];
+            v[r] = cf{n.x + tp_n[r].x * s_n[r], n.y + tp_n[r].y * s_nyq_n};
+        }
         store_spec(a, t);
         prefetch_spec(a, t + 1);
 #pragma unroll
         for (int q = 0; q < E; ++q) acc[q] = acc[q] + v[q];
-        store_block(a, a.y_out, t, &acc[0]);
-#pragma unroll
-        for (int q = 0; q + HB < E; ++q) acc[q] = acc[q + HB];
+        store_block(a, a.y_out, t, acc, 0);
+        shift_rows(acc);
     }
 
     // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
@@ -406,10 +426,14 @@ struct Engine {
     GLV_HD void ph3_write(cf* w) { F::mirror_store(v, w, lane); }
 
     GLV_HD void ph4(const cf* r, cf* w) {
-        cf m[E];
-        F::mirror_load(m, r, mbase);
-        F::split_inv(v, m, tab, lane);
-        F::inv_c(v, w, lane);
+#pragma unroll
+        for (int q0 = 0; q0 < E; q0 += CH) {
+            cf m[CH];
+            F::template mirror_load_part<CH>(m, r, mbase, q0);
+            F::template split_inv_part<CH>(v, m, tab, lane, q0);
+            if (CH < E) GLV_SCHED_FENCE();
+        }
+        F::inv_c(v, tab, w, lane);
     }
     GLV_HD void ph5_read(const cf* r) { F::inv_b(v, tab, r, lane); }
     GLV_HD void ph5_write(cf* w) { F::inv_b_store(v, w, lane); }
@@ -423,16 +447,17 @@ struct Engine {
             acc[q].x = fmaf(v[q].x, wn.x, acc[q].x);
             acc[q].y = fmaf(v[q].y, wn.y, acc[q].y);
         }
-        store_block(a, a.y_out, t, &acc[0]);
+        store_block(a, a.y_out, t, acc, 0);
+        shift_rows(acc);
 #pragma unroll
-        for (int q = 0; q + HB < E; ++q) acc[q] = acc[q + HB];
+        for (int s2 = 0; s2 < A; ++s2)
 #pragma unroll
-        for (int q = E - HB; q < E; ++q) acc[q] = cf{0.f, 0.f};
+            for (int r = 8 - HB; r < 8; ++r) acc[r + 8 * s2] = cf{0.f, 0.f};
     }
     // what is left after the last frame belongs to blocks t_end .. t_end+R-2
     GLV_HD void flush_tails(const IterArgs& a) {
 #pragma unroll
-        for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out_tail, run.t_end + q, &acc[q * HB]);
+        for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out_tail, run.t_end + q, acc, q * HB);
     }
 };
 

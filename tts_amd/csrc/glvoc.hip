@@ -712,8 +712,10 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     *out = nullptr;
     if (n_fft != 1024 && n_fft != 2048)
         return fail(GLV_ERR_UNSUPPORTED, "n_fft %d not supported (1024 or 2048)", n_fft);
-    if (hop != 128 && hop != 256 && hop != 512)
-        return fail(GLV_ERR_UNSUPPORTED, "hop %d not supported (128, 256 or 512)", hop);
+    // the hop is 1, 2 or 4 rows of n_fft/8 samples (overlap factor 8, 4 or 2)
+    if (hop != n_fft / 8 && hop != n_fft / 4 && hop != n_fft / 2)
+        return fail(GLV_ERR_UNSUPPORTED, "hop %d not supported for n_fft %d (n_fft/8, n_fft/4 or n_fft/2)",
+                    hop, n_fft);
     if (win_length < 2 || win_length > n_fft)
         return fail(GLV_ERR_INVALID, "win_length %d outside [2, n_fft]", win_length);
     if (n_mels < 1 || max_frames < 2 || max_batch < 1)
@@ -730,7 +732,7 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     p->max_batch = max_batch;
     p->device = device;
     p->A = n_fft / 1024;
-    p->HB = hop / 128;
+    p->HB = hop / (n_fft / 8);
     p->R = n_fft / hop;
     p->P = n_fft / 2;
     p->F = p->P + 1;

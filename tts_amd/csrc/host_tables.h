@@ -14,7 +14,7 @@
 namespace glv {
 
 struct HostTables {
-    std::vector<cf> fft;      // twA | twB | twP | win   (Geo<A>::TABLES)
+    std::vector<cf> fft;      // twA | twB | twC | twP | win   (Geo<A>::TABLES)
     std::vector<float> w2;    // squared window, N
     std::vector<float> iwss;  // reciprocal complete window-sum-square, H
     std::vector<float> iwss_head;  // [R-1][H] blocks 0..R-2: only frames 0..j exist
@@ -40,11 +40,12 @@ HostTables build_tables(int hop, int win_length) {
     t.fft.resize(G::TABLES);
     cf* twA = t.fft.data();
     cf* twB = twA + G::TW_A;
-    cf* twP = twB + G::TW_B;
+    cf* twC = twB + G::TW_B;
+    cf* twP = twC + G::TW_C;
     cf* win = twP + G::TW_P;
-    for (int k0 = 1; k0 < G::E; ++k0)
+    for (int k0 = 1; k0 < 8; ++k0)
         for (int lane = 0; lane < 64; ++lane) {
-            const double th = 2.0 * pi * (double)(k0 * lane) / G::P;
+            const double th = 2.0 * pi * (double)(k0 * lane) / 512.0;
             twA[(k0 - 1) * 64 + lane] = cf{(float)cos(th), (float)-sin(th)};
         }
     for (int k1 = 1; k1 < 8; ++k1)
@@ -52,6 +53,10 @@ HostTables build_tables(int hop, int win_length) {
             const double th = 2.0 * pi * (double)(k1 * n0) / 64.0;
             twB[(k1 - 1) * 8 + n0] = cf{(float)cos(th), (float)-sin(th)};
         }
+    for (int i = 0; i < G::TW_C; ++i) {
+        const double th = 2.0 * pi * (double)G::bin(i >> 6, i & 63) / G::P;
+        twC[i] = cf{(float)cos(th), (float)-sin(th)};
+    }
     for (int reg = 0; reg < G::E; ++reg)
         for (int lane = 0; lane < 64; ++lane) {
             const double th = 2.0 * pi * (double)G::bin(reg, lane) / G::N;
@@ -60,8 +65,8 @@ HostTables build_tables(int hop, int win_length) {
     const std::vector<double> w = padded_hann(G::N, win_length);
     for (int reg = 0; reg < G::E; ++reg)
         for (int lane = 0; lane < 64; ++lane) {
-            const int m = 64 * reg + lane;
-            win[reg * 64 + lane] = cf{(float)w[2 * m], (float)w[2 * m + 1]};
+            const int s = G::sample(reg, lane);
+            win[reg * 64 + lane] = cf{(float)w[s], (float)w[s + 1]};
         }
     t.w2.resize(G::N);
     for (int n = 0; n < G::N; ++n) t.w2[n] = (float)(w[n] * w[n]);

@@ -1,22 +1,25 @@
-// One-wavefront real FFT for gfx950: a frame of N = 128*E real samples (E = 8 or
-// 16) lives in the registers of ONE 64-lane wave as P = N/2 = 64*E complex
-// values, E per lane.  Three register-resident DFT passes (radix E, 8, 8) are
-// separated by two lane<->register transposes through a wave-private LDS
-// buffer; a third LDS exchange fetches the mirror bin P-k that the
-// real-from-complex split needs.  No workgroup barrier is involved: a wave
-// only ever reads LDS words it wrote itself.
+// One-wavefront real FFT for gfx950.  A frame of N = 1024*A real samples (A = 1 or 2) lives
+// in the registers of ONE 64-lane wave as P = N/2 = 512*A complex values, E = 8*A per lane.
 //
-// Index conventions (A = E/8):
-//   time side   : complex index m = 64*n2 + lane, register n2 in [0,E),
-//                 lane = 8*n1 + n0.  z[m] = x[2m] + i*x[2m+1].
-//   freq side   : k = k0a + A*k0b + E*k1 + 8E*k2 with register = A*k2 + k0a and
-//                 lane = 8*k0b + k1  (k0 = A*k0b + k0a is the radix-E digit).
-//   "native" spectrum order: the (register, lane) order of the freq side; bin 0
-//   carries the two real bins DC and Nyquist packed as (re, im).
+// The complex transform of size P is A interleaved transforms of size 512 (decimation in
+// time by A), each done as three register-resident radix-8 passes separated by two
+// lane<->register transposes through a wave-private LDS buffer; for A = 2 the two halves
+// meet in one radix-2 butterfly that needs no data movement, because both halves hold bin
+// k in the same (register, lane).  A third LDS exchange fetches the mirror bin P-k that the
+// real-from-complex split needs.  No workgroup barrier is involved: a wave only ever reads
+// LDS words it wrote itself.
 //
-// The code is plain C++ on purpose: every function is usable from a host
-// emulation in which the 64 lanes are a loop (tests/csrc), which is how the
-// index algebra is checked without a GPU.
+// Index conventions (register q = r + 8a, r in [0,8), a in [0,A)):
+//   time side   : row r, sub-sequence a, lane l hold z_a[64r + l] = (x[s], x[s+1]) with
+//                 s = 128A*r + 2A*l + 2a: a lane's share of a row is 2A contiguous floats,
+//                 a row is 128A contiguous samples, a hop of H samples is H/(128A) rows.
+//   freq side   : lane = 8*k0 + k1, register q = k2 + 8h hold bin k = k0 + 8*k1 + 64*k2 + 512*h.
+//   "native" spectrum order: the (register, lane) order of the freq side; bin 0 carries the
+//   two real bins DC and Nyquist packed as (re, im).
+//
+// The code is plain C++ on purpose: every function is usable from a host emulation in which
+// the 64 lanes are a loop (tests/csrc), which is how the index algebra is checked without a
+// GPU.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -95,35 +98,6 @@ struct Dft<8, INV> {
     }
 };
 
-template <bool INV>
-struct Dft<16, INV> {
-    static GLV_HD void run(cf (&v)[16]) {
-        // W16^n = (cos(pi n/8), -sin(pi n/8)), n = 1..7
-        constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
-        constexpr float h = 0.70710678118654752440f;
-        cf b[8], c[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            b[n] = v[n] + v[n + 8];
-            c[n] = v[n] - v[n + 8];
-        }
-        c[1] = twmul<INV>(c[1], cf{c1, -s1});
-        c[2] = twmul<INV>(c[2], cf{h, -h});
-        c[3] = twmul<INV>(c[3], cf{s1, -c1});
-        c[4] = rot90<INV>(c[4]);
-        c[5] = twmul<INV>(c[5], cf{-s1, -c1});
-        c[6] = twmul<INV>(c[6], cf{-h, -h});
-        c[7] = twmul<INV>(c[7], cf{-c1, -s1});
-        Dft<8, INV>::run(b);
-        Dft<8, INV>::run(c);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[2 * k] = b[k];
-            v[2 * k + 1] = c[k];
-        }
-    }
-};
-
 // ---------------------------------------------------------------------------
 // Geometry of the wave FFT and of its LDS exchange buffer (unit = one cf).
 // ---------------------------------------------------------------------------
@@ -132,34 +106,37 @@ struct Geo {
     static constexpr int E = 8 * A;      // complex values per lane
     static constexpr int P = 64 * E;     // complex FFT size = n_fft / 2
     static constexpr int N = 2 * P;      // n_fft
-    // transpose 1: slot = k0a*X1 + 72*k0b + 8*n1 + n0   (72 = 64 + 8 keeps the
+    static constexpr int ROW = 128 * A;  // samples per row (one register of every sub-sequence)
+    // transpose 1 (per sub-sequence): slot = 72*k0 + 8*n1 + n0   (72 = 64 + 8 keeps the
     //   strided side on distinct banks)
     static constexpr int X1 = 7 * 72 + 64;
-    // transpose 2: slot = k0a*X2 + 8*k0b + k1 + 65*n0
+    // transpose 2: slot = 8*k0 + k1 + 65*n0
     static constexpr int X2 = 65 * 7 + 64 + 1;
-    // mirror: slot = reg*64 + lane, plus row E holding a copy of bin 0
-    static constexpr int X3 = (E + 1) * 64;
-    static constexpr int XBUF = (A * X1 > X3) ? (A * X1 > A * X2 ? A * X1 : A * X2)
-                                              : (X3 > A * X2 ? X3 : A * X2);
+    // mirror (per half h): slot = k2*64 + lane, plus row 8 holding a copy of a bin 0
+    static constexpr int X3 = 9 * 64;
+    static constexpr int XBUF = A * X3;  // X3 >= X1 >= X2
     // table sizes (cf units)
-    static constexpr int TW_A = (E - 1) * 64;  // [k0-1][lane]   W_P^(k0*lane)
-    static constexpr int TW_B = 7 * 8;         // [k1-1][n0]     W_64^(k1*n0)
-    static constexpr int TW_P = E * 64;        // [reg][lane]    0.5 * W_N^k
-    static constexpr int WIN = E * 64;         // [reg][lane]    (w[2m], w[2m+1])
-    static constexpr int TABLES = TW_A + TW_B + TW_P + WIN;
+    static constexpr int TW_A = 7 * 64;             // [k0-1][lane]  W_512^(k0*lane)
+    static constexpr int TW_B = 7 * 8;              // [k1-1][n0]    W_64^(k1*n0)
+    static constexpr int TW_C = (A - 1) * 8 * 64;   // [k2][lane]    W_P^k, k < 512 (A = 2)
+    static constexpr int TW_P = E * 64;             // [q][lane]     0.5 * W_N^bin
+    static constexpr int WIN = E * 64;              // [q][lane]     (w[s], w[s+1])
+    static constexpr int TABLES = TW_A + TW_B + TW_C + TW_P + WIN;
 
-    // bin index held by (reg, lane) on the frequency side
-    static GLV_HD int bin(int reg, int lane) {
-        return (reg % A) + A * (lane >> 3) + E * (lane & 7) + 8 * E * (reg / A);
+    // bin held by (register, lane) on the frequency side
+    static GLV_HD int bin(int q, int lane) {
+        return (lane >> 3) + 8 * (lane & 7) + 64 * (q & 7) + 512 * (q >> 3);
     }
-    // slot (relative to row A*(7-k2)+k0a... see mirror_read) where lane finds the
-    // mirror partner of its register with low digit k0a
-    static GLV_HD int mirror_base(int k0a, int lane) {
-        const int low = k0a + A * (lane >> 3) + E * (lane & 7);
-        if (low == 0) return A * 64;  // lane 0: partner lives in its own lane, A rows up
-        const int lp = 8 * E - low;
-        const int k0bp = (lp / A) % 8, k1p = lp / E;
-        return 8 * k0bp + k1p;
+    // first sample (of two) held by (register, lane) on the time side, relative to the frame
+    static GLV_HD int sample(int q, int lane) { return ROW * (q & 7) + 2 * A * lane + 2 * (q >> 3); }
+    // lane offset (slots) at which a lane finds the mirror partners of its bins inside the
+    // other half's mirror region: partner of local bin kl is 512 - kl, i.e. row 7-k2 at this
+    // offset - except for lane 0, whose partners sit in its own column one row further down
+    static GLV_HD int mirror_base(int lane) {
+        const int low = (lane >> 3) + 8 * (lane & 7);
+        if (low == 0) return 64;
+        const int lp = 64 - low;
+        return 8 * (lp & 7) + (lp >> 3);
     }
 };
 
@@ -167,27 +144,33 @@ struct Geo {
 struct Tables {
     const cf* twA;
     const cf* twB;
+    const cf* twC;
     const cf* twP;
     const cf* win;
 };
 
 // ---------------------------------------------------------------------------
-// Forward complex FFT of the wave's P values: the three phases between LDS
-// exchanges.  `w` = buffer this phase writes, `r` = buffer it reads (the same
-// buffer on the device; the host emulation alternates two).
+// The phases of the transform between LDS exchanges.  `w` = buffer this phase writes, `r` =
+// buffer it reads (the same buffer on the device; the host emulation alternates two).
 // ---------------------------------------------------------------------------
 template <int A>
 struct WaveFft {
     using G = Geo<A>;
     static constexpr int E = G::E;
 
-    // ---- forward ----
+    // ---- forward: A interleaved 512-point transforms ----
     static GLV_HD void fwd_a(cf (&v)[E], const Tables& t, cf* w, int lane) {
-        Dft<E, false>::run(v);
 #pragma unroll
-        for (int k0 = 1; k0 < E; ++k0) v[k0] = cmul(v[k0], t.twA[(k0 - 1) * 64 + lane]);
+        for (int a = 0; a < A; ++a) {
+            cf u[8];
 #pragma unroll
-        for (int k0 = 0; k0 < E; ++k0) w[(k0 % A) * G::X1 + 72 * (k0 / A) + lane] = v[k0];
+            for (int n2 = 0; n2 < 8; ++n2) u[n2] = v[n2 + 8 * a];
+            Dft<8, false>::run(u);
+#pragma unroll
+            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmul(u[k0], t.twA[(k0 - 1) * 64 + lane]);
+#pragma unroll
+            for (int k0 = 0; k0 < 8; ++k0) w[a * G::X1 + 72 * k0 + lane] = u[k0];
+        }
     }
     static GLV_HD void fwd_b(cf (&v)[E], const Tables& t, const cf* r, int lane) {
         const int hi = lane >> 3, lo = lane & 7;
@@ -200,7 +183,7 @@ struct WaveFft {
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmul(u[k1], t.twB[(k1 - 1) * 8 + lo]);
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) v[A * k1 + a] = u[k1];
+            for (int k1 = 0; k1 < 8; ++k1) v[k1 + 8 * a] = u[k1];
         }
     }
     static GLV_HD void fwd_b_store(const cf (&v)[E], cf* w, int lane) {
@@ -208,9 +191,11 @@ struct WaveFft {
 #pragma unroll
         for (int a = 0; a < A; ++a)
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) w[a * G::X2 + 8 * hi + k1 + 65 * lo] = v[A * k1 + a];
+            for (int k1 = 0; k1 < 8; ++k1) w[a * G::X2 + 8 * hi + k1 + 65 * lo] = v[k1 + 8 * a];
     }
-    static GLV_HD void fwd_c(cf (&v)[E], const cf* r, int lane) {
+    // last pass, then (A = 2) the radix-2 butterfly that joins the two sub-sequences:
+    // Z[k] = E[k] + W_P^k O[k], Z[k + 512] = E[k] - W_P^k O[k]
+    static GLV_HD void fwd_c(cf (&v)[E], const Tables& t, const cf* r, int lane) {
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
@@ -218,39 +203,60 @@ struct WaveFft {
             for (int n0 = 0; n0 < 8; ++n0) u[n0] = r[a * G::X2 + lane + 65 * n0];
             Dft<8, false>::run(u);
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) v[A * k2 + a] = u[k2];
+            for (int k2 = 0; k2 < 8; ++k2) v[k2 + 8 * a] = u[k2];
+        }
+        if (A == 2) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const cf e = v[k2], o = cmul(v[k2 + 8 * (A - 1)], t.twC[k2 * 64 + lane]);
+                v[k2] = e + o;
+                v[k2 + 8 * (A - 1)] = e - o;
+            }
         }
     }
 
     // ---- mirror exchange: everybody publishes, then reads bin P-k ----
+    // Half h (registers 8h..8h+7) is published in region h; the partner of a bin of half h
+    // lives in half A-1-h.  Row 8 of a region holds the bin 0 the OTHER region's lane 0 needs.
     static GLV_HD void mirror_store(const cf (&v)[E], cf* w, int lane) {
 #pragma unroll
-        for (int reg = 0; reg < E; ++reg) w[reg * 64 + lane] = v[reg];
-        if (lane == 0) w[E * 64] = v[0];
-    }
-    // mbase[a] = Geo::mirror_base(a, lane)
-    static GLV_HD void mirror_load(cf (&m)[E], const cf* r, const int (&mbase)[A]) {
+        for (int q = 0; q < E; ++q) w[(q >> 3) * G::X3 + (q & 7) * 64 + lane] = v[q];
+        if (lane == 0) {
 #pragma unroll
-        for (int reg = 0; reg < E; ++reg) {
-            const int a = reg % A, k2 = reg / A;
-            m[reg] = r[(A * (7 - k2) + a) * 64 + mbase[a]];
+            for (int h = 0; h < A; ++h) w[(A - 1 - h) * G::X3 + 8 * 64] = v[8 * h];
         }
     }
+    // mbase = Geo::mirror_base(lane).  The *_part forms handle registers q0 .. q0+NQ-1 only
+    // (m[i] pairs with v[q0 + i]), so a caller can bound how many partners are live at once.
+    template <int NQ>
+    static GLV_HD void mirror_load_part(cf (&m)[NQ], const cf* r, int mbase, int q0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int h = (q0 + i) >> 3, k2 = (q0 + i) & 7;
+            m[i] = r[(A - 1 - h) * G::X3 + (7 - k2) * 64 + mbase];
+        }
+    }
+    static GLV_HD void mirror_load(cf (&m)[E], const cf* r, int mbase) { mirror_load_part<E>(m, r, mbase, 0); }
 
     // ---- real <-> half-complex split ----
     // X[k] = 0.5*(Zk + conj Zm) - i * (0.5 W_N^k) * (Zk - conj Zm); bin 0 packs
     // (DC, Nyquist) = (Re Z0 + Im Z0, Re Z0 - Im Z0).
     static GLV_HD void split_fwd(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane) {
+        split_fwd_part<E>(v, m, t, lane, 0);
+    }
+    template <int NQ>
+    static GLV_HD void split_fwd_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
 #pragma unroll
-        for (int reg = 0; reg < E; ++reg) {
-            const cf a = v[reg], b = m[reg];
+        for (int i = 0; i < NQ; ++i) {
+            const int q = q0 + i;
+            const cf a = v[q], b = m[i];
             const cf s = {a.x + b.x, a.y - b.y};
             const cf d = {a.x - b.x, a.y + b.y};
-            const cf tw = t.twP[reg * 64 + lane];
+            const cf tw = t.twP[q * 64 + lane];
             const cf u = cmul(tw, d);
             cf x = {0.5f * s.x + u.y, 0.5f * s.y - u.x};
-            if (reg == 0 && lane == 0) x = cf{a.x + a.y, a.x - a.y};
-            v[reg] = x;
+            if (q == 0 && lane == 0) x = cf{a.x + a.y, a.x - a.y};
+            v[q] = x;
         }
     }
     // Z[k] = (Xk + conj Xm) + i * conj(W_N^k) * (Xk - conj Xm)   (twP holds 0.5 W,
@@ -258,26 +264,40 @@ struct WaveFft {
     // The result is 2x the half-size spectrum; callers fold the factor into the
     // 1/N of the inverse transform.
     static GLV_HD void split_inv(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane) {
+        split_inv_part<E>(v, m, t, lane, 0);
+    }
+    template <int NQ>
+    static GLV_HD void split_inv_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
 #pragma unroll
-        for (int reg = 0; reg < E; ++reg) {
-            const cf a = v[reg], b = m[reg];
+        for (int i = 0; i < NQ; ++i) {
+            const int q = q0 + i;
+            const cf a = v[q], b = m[i];
             const cf s = {a.x + b.x, a.y - b.y};
             const cf d = {a.x - b.x, a.y + b.y};
-            const cf tw = t.twP[reg * 64 + lane];
+            const cf tw = t.twP[q * 64 + lane];
             const cf u = cmulc(d, tw);  // d * conj(0.5 W)
             cf z = {s.x - 2.0f * u.y, s.y + 2.0f * u.x};
-            if (reg == 0 && lane == 0) z = cf{a.x + a.y, a.x - a.y};
-            v[reg] = z;
+            if (q == 0 && lane == 0) z = cf{a.x + a.y, a.x - a.y};
+            v[q] = z;
         }
     }
 
     // ---- inverse (unnormalised) ----
-    static GLV_HD void inv_c(cf (&v)[E], cf* w, int lane) {
+    // (A = 2) undo the joining butterfly: E = Z[k] + Z[k+512], O = (Z[k] - Z[k+512]) conj(W_P^k)
+    static GLV_HD void inv_c(cf (&v)[E], const Tables& t, cf* w, int lane) {
+        if (A == 2) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const cf z0 = v[k2], z1 = v[k2 + 8 * (A - 1)];
+                v[k2] = z0 + z1;
+                v[k2 + 8 * (A - 1)] = cmulc(z0 - z1, t.twC[k2 * 64 + lane]);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) u[k2] = v[A * k2 + a];
+            for (int k2 = 0; k2 < 8; ++k2) u[k2] = v[k2 + 8 * a];
             Dft<8, true>::run(u);
 #pragma unroll
             for (int n0 = 0; n0 < 8; ++n0) w[a * G::X2 + lane + 65 * n0] = u[n0];
@@ -294,7 +314,7 @@ struct WaveFft {
             for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmulc(u[k1], t.twB[(k1 - 1) * 8 + lo]);
             Dft<8, true>::run(u);
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) v[A * n1 + a] = u[n1];
+            for (int n1 = 0; n1 < 8; ++n1) v[n1 + 8 * a] = u[n1];
         }
     }
     static GLV_HD void inv_b_store(const cf (&v)[E], cf* w, int lane) {
@@ -302,14 +322,20 @@ struct WaveFft {
 #pragma unroll
         for (int a = 0; a < A; ++a)
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) w[a * G::X1 + 72 * hi + 8 * n1 + lo] = v[A * n1 + a];
+            for (int n1 = 0; n1 < 8; ++n1) w[a * G::X1 + 72 * hi + 8 * n1 + lo] = v[n1 + 8 * a];
     }
     static GLV_HD void inv_a(cf (&v)[E], const Tables& t, const cf* r, int lane) {
 #pragma unroll
-        for (int k0 = 0; k0 < E; ++k0) v[k0] = r[(k0 % A) * G::X1 + 72 * (k0 / A) + lane];
+        for (int a = 0; a < A; ++a) {
+            cf u[8];
 #pragma unroll
-        for (int k0 = 1; k0 < E; ++k0) v[k0] = cmulc(v[k0], t.twA[(k0 - 1) * 64 + lane]);
-        Dft<E, true>::run(v);
+            for (int k0 = 0; k0 < 8; ++k0) u[k0] = r[a * G::X1 + 72 * k0 + lane];
+#pragma unroll
+            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmulc(u[k0], t.twA[(k0 - 1) * 64 + lane]);
+            Dft<8, true>::run(u);
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) v[n2 + 8 * a] = u[n2];
+        }
     }
 };
 
