@@ -406,3 +406,42 @@ def test_recompute_variant_matches(voc, O, lj001, n_fft, hop, frames):
         assert rel_l2(y1, snaps[k]) < 1e-3, k
         assert np.max(np.abs(sc - sc_ref[:k]) / sc_ref[:k]) < 1e-2
     plan.close()
+
+
+def test_drop_in_44k_128_mel_variant(voc, O):
+    """The 44.1 kHz / 128-mel / n_fft 2048 / hop 512 configuration (fmax = Nyquist) through the
+    reference signature against the oracle with the same seeded phase."""
+    from helpers import synthetic_mel
+    mel = synthetic_mel(7, 150, n_mels=128)
+    kw = dict(sr=44100, n_fft=2048, hop_length=512, win_length=2048, n_mels=128, fmax=None)
+    y1 = voc.mel_to_audio_griffin_lim(mel, MEAN, STD, n_iter=8, init_phase=11, **kw)
+    y2 = O.mel_to_audio_griffin_lim(mel, MEAN, STD, n_iter=8, random_state=11, **kw)
+    assert y1.shape == y2.shape == (512 * 149,)
+    assert rel_l2(y1, y2) < 1e-3
+    # the inverted magnitudes alone: 1e-4
+    plan = voc.get_plan(2048, 512, 2048, 128, 150, 1)
+    plan.set_mel_basis(44100, 0.0, None)
+    S = plan.mel_invert(dev(mel[None]), MEAN, STD)[0].cpu().numpy()
+    assert rel_l2(S, O.mel_invert(mel, MEAN, STD, sr=44100, n_fft=2048, n_mels=128, fmax=None).T) < 1e-4
+
+
+def test_acoustic_model_feeds_vocoder_on_device(voc):
+    """Phoneme ids -> FastSpeech-style mel producer -> vocoder with the mel staying on the GPU
+    equals the reference's flow (predict on one side, numpy mel handed to the vocoder,
+    test.py:188-192) bit for bit, given the same initial phase."""
+    from tts_amd.acoustic import FastSpeechAcousticModel, synthesize
+    torch.manual_seed(0)
+    model = FastSpeechAcousticModel(72).to("cuda")
+    rng = np.random.default_rng(0)
+    ids = np.concatenate([rng.integers(1, 72, 40), np.zeros(10, np.int64)])[None]
+    durations = np.log(np.concatenate([rng.integers(2, 9, 40), np.ones(10)]).astype(np.float32))[None]
+    frames = int(np.round(np.exp(durations)).sum())
+    phase = 2 * np.pi * np.random.default_rng(4).random((513, frames))
+    kw = dict(n_fft=1024, win_length=1024, hop_length=256, n_iter=8, init_phase=phase)
+    audio, mel = synthesize(model, ids, durations, MEAN, STD, return_mel=True, **kw)
+    assert audio.is_cuda and mel.is_cuda and mel.shape == (frames, 80)
+    assert audio.shape == (256 * (frames - 1),)
+    host = voc.mel_to_audio_griffin_lim(mel.cpu().numpy(), MEAN, STD, **kw)
+    assert np.array_equal(audio.cpu().numpy(), host)
+    # a random-init model emits a very quiet mel, so the 1e-6 of the peak normalisation shows
+    assert np.isfinite(host).all() and 0.9 < np.abs(host).max() <= 1.0

@@ -38,6 +38,9 @@
 #ifndef GLV_SPLIT_CHUNK
 #define GLV_SPLIT_CHUNK 8
 #endif
+#ifndef GLV_SPLIT_CHUNK_A1
+#define GLV_SPLIT_CHUNK_A1 8
+#endif
 // Keeps the compiler from moving instructions across this point (it would otherwise hoist
 // every load of a phase to its top and hold all results in registers at once).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -131,7 +134,7 @@ struct Engine {
     static constexpr int H = ROW * HB;   // hop
     static constexpr int R = 8 / HB;     // frames covering one sample
     static constexpr int HV = HB * A;    // registers per hop
-    static constexpr int CH = (A == 1) ? E : GLV_SPLIT_CHUNK;  // registers per split chunk
+    static constexpr int CH = (A == 1) ? GLV_SPLIT_CHUNK_A1 : GLV_SPLIT_CHUNK;  // registers per split chunk
     static constexpr float kTiny = 1.17549435e-38f;
     // The previous spectrum is fetched a frame ahead (E more live registers) or on demand.
     static constexpr bool kPrefetchTp = GLV_PREFETCH_TP_ALL || (A == 1);

@@ -418,10 +418,14 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
     if isinstance(mel_db, (list, tuple)):
         lengths = [int(m.shape[0]) for m in mel_db]
         t_max = max(lengths)
-        packed = np.zeros((len(mel_db), t_max, n_mels), dtype=np.float32)
-        for i, m in enumerate(mel_db):
-            packed[i, : lengths[i]] = m.cpu().numpy() if isinstance(m, torch.Tensor) else m
-        mel = torch.from_numpy(packed)
+        if all(isinstance(m, torch.Tensor) and m.is_cuda for m in mel_db):
+            # mels produced on the device are padded there
+            mel = torch.nn.utils.rnn.pad_sequence([m.detach().float() for m in mel_db], batch_first=True)
+        else:
+            packed = np.zeros((len(mel_db), t_max, n_mels), dtype=np.float32)
+            for i, m in enumerate(mel_db):
+                packed[i, : lengths[i]] = m.detach().cpu().numpy() if isinstance(m, torch.Tensor) else m
+            mel = torch.from_numpy(packed)
     else:
         mel = mel_db if isinstance(mel_db, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(mel_db, dtype=np.float32))
