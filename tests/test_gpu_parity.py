@@ -445,3 +445,28 @@ def test_acoustic_model_feeds_vocoder_on_device(voc):
     assert np.array_equal(audio.cpu().numpy(), host)
     # a random-init model emits a very quiet mel, so the 1e-6 of the peak normalisation shows
     assert np.isfinite(host).all() and 0.9 < np.abs(host).max() <= 1.0
+
+
+def test_drop_in_with_nnls_inversion(voc, O, lj001):
+    """inversion="nnls": a non-negative spectrogram whose mel residual is below that of the
+    clipped pinv product it starts from, then the same Griffin-Lim."""
+    mel, mean, std = lj001
+    mel = mel[:96]
+    plan = voc.get_plan(1024, 256, 1024, 80, 96, 1)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    from tts_amd.vocoder import _invert_mel
+    S = _invert_mel(plan, dev(mel[None]), mean, std, "nnls", 200)[0].cpu().numpy().astype(np.float64)
+    assert S.min() >= 0.0
+    basis = O.mel_filterbank(22050, 1024, n_mels=80, fmax=8000).astype(np.float64)
+    target = O.db_to_power((mel * std + mean).T).astype(np.float64)
+    start = np.clip(O.mel_invert(mel, mean, std, n_fft=1024), 0, None)
+    res = np.linalg.norm(basis @ S.T - target) / np.linalg.norm(target)
+    res0 = np.linalg.norm(basis @ start - target) / np.linalg.norm(target)
+    assert res < res0, (res, res0)
+    kw = dict(n_fft=1024, win_length=1024, n_iter=8, init_phase=5)
+    y = voc.mel_to_audio_griffin_lim(mel, mean, std, inversion="nnls", **kw)
+    y2 = O.griffinlim(S.T.astype(np.float32), n_iter=8, hop_length=256, win_length=1024, n_fft=1024,
+                      random_state=5)
+    assert rel_l2(y, O.peak_normalise(y2)) < 1e-3
+    with pytest.raises(ValueError):
+        voc.mel_to_audio_griffin_lim(mel, mean, std, inversion="lbfgs")

@@ -359,9 +359,22 @@ def _phase_tensor(init_phase, n_bins, frames, device):
     return torch.from_numpy(pair).to(device)
 
 
+def _invert_mel(plan, mel, mean, std, inversion, nnls_steps):
+    """(B, T, n_mels) normalised dB -> (B, T, F) what the reference calls linear_spec."""
+    if inversion == "pinv":
+        return plan.mel_invert(mel, float(mean), float(std))
+    if inversion == "nnls":
+        # the non-negative least-squares solution takes the place of the pinv product; like it,
+        # it is in the power domain and handed to Griffin-Lim as it is
+        power = torch.pow(10.0, 0.1 * (mel * float(std) + float(mean)))
+        return plan.mel_invert_nnls(power, n_steps=nnls_steps, power=1.0)
+    raise ValueError(f"inversion must be 'pinv' or 'nnls', got {inversion!r}")
+
+
 def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length=256, win_length=2048,
                              n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, init_phase=None,
-                             device=None, return_tensor=False, verbose=False):
+                             inversion="pinv", nnls_steps=200, device=None, return_tensor=False,
+                             verbose=False):
     """Normalised-dB mel (T, n_mels) -> peak-normalised waveform of hop_length*(T-1)
     samples, as reference vocoder/mel_audio.py:112-132 computes it:
     denormalise, dB->power, pinv(mel basis) @ mel, librosa.griffinlim(n_iter=60,
@@ -372,6 +385,9 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
       init_phase         None: fresh random phase per call (unseeded, like the
                          reference); int: ``np.random.default_rng(seed)`` phase;
                          (F, T) array of phasors or radians: that phase.
+      inversion          "pinv" (reference: pinv(mel basis) @ mel power, may be negative) or
+                         "nnls" (non-negative least squares, `nnls_steps` projected-gradient
+                         steps from the clipped pinv product, as librosa's mel_to_stft starts).
       device             torch device (default: current ROCm device).
       return_tensor      return the device tensor instead of a numpy array.
       verbose            print what the reference prints (:130-131).
@@ -386,7 +402,7 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, 0.0, fmax)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
-    S = plan.mel_invert(mel, float(mean), float(std))
+    S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
     if init_phase is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
         phase0 = None
@@ -407,7 +423,8 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
 
 def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop_length=256,
                       win_length=2048, n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, phase0=None,
-                      seed=0, device=None, return_sc=False, normalize=True):
+                      seed=0, inversion="pinv", nnls_steps=200, device=None, return_sc=False,
+                      normalize=True):
     """Batched mel_to_audio_griffin_lim.
 
     ``mel_db``: (B, T, n_mels) array/tensor (rows past lengths[b] ignored) or a
@@ -437,7 +454,7 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
     plan = get_plan(n_fft, hop_length, win_length, n_mels, t_max, b, device)
     plan.set_mel_basis(sr, 0.0, fmax)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous()
-    S = plan.mel_invert(mel, float(mean), float(std))
+    S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
     res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
                           return_sc=return_sc)
     y, sc = res if return_sc else (res, None)
