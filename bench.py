@@ -98,6 +98,8 @@ def main():
                     help="measurement aid: all utterances share one utterance's memory (cache-resident loop)")
     ap.add_argument("--traffic-only", action="store_true",
                     help="measurement aid: iteration kernels move their data but compute nothing")
+    ap.add_argument("--unfused", action="store_true",
+                    help="mel inversion, Griffin-Lim and peak normalisation as three library calls")
     ap.add_argument("--cpu-utts", type=int, default=32)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -146,9 +148,14 @@ def main():
     out = torch.empty((args.batch, HOP * (t_max - 1)), dtype=torch.float32, device=device)
 
     def step(i):
-        s = plan.mel_invert(mel, MEAN, STD)
-        plan.griffinlim(s, frames_list, phase0=None, seed=1000 + i, n_iter=N_ITER, momentum=MOMENTUM, out=out)
-        plan.peak_normalize(out, n_samples)
+        if args.unfused:
+            # the three stages as separate library calls (magnitudes pass through a (B, T, F) array)
+            s = plan.mel_invert(mel, MEAN, STD)
+            plan.griffinlim(s, frames_list, phase0=None, seed=1000 + i, n_iter=N_ITER, momentum=MOMENTUM, out=out)
+            plan.peak_normalize(out, n_samples)
+        else:
+            plan.mel_to_audio(mel, MEAN, STD, frames_list, phase0=None, seed=1000 + i, n_iter=N_ITER,
+                              momentum=MOMENTUM, out=out)
 
     def fence():
         torch.cuda.synchronize(device)

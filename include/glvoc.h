@@ -115,6 +115,19 @@ int glv_griffinlim(glv_plan* plan, const float* S_dev, const float* phase0_dev, 
                    void* stream);
 
 /*
+ * The whole of mel_to_audio_griffin_lim (reference vocoder/mel_audio.py:112-132) in one call:
+ * glv_mel_invert + glv_griffinlim + glv_peak_normalize, with the same results bit for bit, but
+ * the inverted magnitudes go straight from the matrix product into the iteration state
+ * (no (batch, frames, F) array in between) and the peak is gathered while the waveform is
+ * written.  Arguments as for the three calls; peak_eps is the reference's 1e-6, or negative
+ * to leave the waveform un-normalised.
+ */
+int glv_mel_to_audio(glv_plan* plan, const float* mel_db_dev, float mean, float std,
+                     const float* phase0_dev, uint64_t seed, const int* n_frames_host, int batch,
+                     int frames_stride, int n_iter, float momentum, float peak_eps, float* y_dev,
+                     int64_t y_stride, float* sc_curve_dev, void* stream);
+
+/*
  * audio / (max|audio| + eps) per utterance (reference vocoder/mel_audio.py:129,
  * eps = 1e-6).  In place on y_dev rows of n_samples_host[b] samples.
  */

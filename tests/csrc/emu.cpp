@@ -264,6 +264,11 @@ int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const flo
     });
 }
 
+// u[i] = the generator's value for element idx0 + i (the device-side initial phase stream)
+void emu_counter_uniform(uint64_t seed, uint64_t idx0, int n, float* u) {
+    for (int i = 0; i < n; ++i) u[i] = counter_uniform(seed, idx0 + (uint64_t)i);
+}
+
 int emu_stft(int n_fft, int hop, int win_length, const float* y, int64_t y_stride, const int* n_frames,
              int batch, int frames_stride, int frames_per_run, float* D) {
     return dispatch(n_fft, hop, [&](auto* tag) {

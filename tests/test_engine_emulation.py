@@ -147,3 +147,26 @@ def test_recompute_mode_is_the_same_iteration(emu, n_fft, hop, win, frames, fpr)
     assert rel_l2(y1[0], y0[0]) < 1e-6
     assert rel_l2(y1[0], y_ref) < 5e-6
     assert np.max(np.abs(sc1[0] - sc_ref) / sc_ref) < 1e-5
+
+
+def test_device_phase_generator_statistics(emu):
+    """The counter generator behind device-drawn initial phases: uniform on [0, 1), no visible
+    correlation between neighbouring elements, between seeds, or across the 2^32 index boundary."""
+    n = 1 << 18
+    def draw(seed, idx0):
+        u = np.empty(n, np.float32)
+        emu.emu_counter_uniform(ctypes.c_uint64(seed), ctypes.c_uint64(idx0), n,
+                                u.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        return u.astype(np.float64)
+    a = draw(0, 0)
+    assert a.min() >= 0.0 and a.max() < 1.0
+    assert abs(a.mean() - 0.5) < 3e-3 and abs(a.var() - 1 / 12) < 2e-3
+    hist = np.histogram(a, bins=64, range=(0, 1))[0]
+    assert np.abs(hist / (n / 64) - 1).max() < 0.1
+    corr = lambda x, y: float(np.corrcoef(x, y)[0, 1])
+    assert abs(corr(a[:-1], a[1:])) < 0.01
+    assert abs(corr(a, draw(1, 0))) < 0.01
+    assert abs(corr(a, draw(0, 1 << 32))) < 0.01
+    assert abs(corr(a, draw(1 << 32, 0))) < 0.01
+    # the phasor sum of n random phases is O(sqrt(n))
+    assert abs(np.exp(2j * np.pi * a).sum()) < 5 * np.sqrt(n)

@@ -470,3 +470,33 @@ def test_drop_in_with_nnls_inversion(voc, O, lj001):
     assert rel_l2(y, O.peak_normalise(y2)) < 1e-3
     with pytest.raises(ValueError):
         voc.mel_to_audio_griffin_lim(mel, mean, std, inversion="lbfgs")
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 256), (2048, 512)])
+def test_single_call_equals_three_calls(voc, n_fft, hop):
+    """glv_mel_to_audio (magnitudes written straight into the iteration state, peak gathered
+    while the waveform is written) against mel_invert + griffinlim + peak_normalize: the same
+    bits, for given and for device-drawn phases, ragged lengths and odd n_mels."""
+    from helpers import synthetic_mel, phasors
+    lens = [70, 33, 64]
+    for n_mels in (80, 37):
+        mel = np.zeros((3, 70, n_mels), np.float32)
+        for b, t in enumerate(lens):
+            mel[b, :t] = synthetic_mel(20 + b, t, n_mels=n_mels)
+        plan = voc.GriffinLimPlan(n_fft, hop, n_fft, n_mels, 70, 3)
+        plan.set_mel_basis(22050, 0.0, 8000)
+        md = dev(mel)
+        ph = np.stack([np.stack([phasors(5 + b, n_fft // 2 + 1, 70).T.real,
+                                 phasors(5 + b, n_fft // 2 + 1, 70).T.imag], -1) for b in range(3)])
+        for phase0, seed in ((dev(np.ascontiguousarray(ph, dtype=np.float32)), 0), (None, 77)):
+            S = plan.mel_invert(md, MEAN, STD)
+            y3, sc3 = plan.griffinlim(S, lens, phase0=phase0, seed=seed, n_iter=5, return_sc=True)
+            n_samples = [hop * (t - 1) for t in lens]
+            raw3 = y3.clone()
+            plan.peak_normalize(y3, n_samples)
+            y1, sc1 = plan.mel_to_audio(md, MEAN, STD, lens, phase0=phase0, seed=seed, n_iter=5, return_sc=True)
+            assert torch.equal(y1, y3)
+            assert torch.equal(sc1, sc3)
+            raw1 = plan.mel_to_audio(md, MEAN, STD, lens, phase0=phase0, seed=seed, n_iter=5, peak_eps=None)
+            assert torch.equal(raw1, raw3)
+        plan.close()

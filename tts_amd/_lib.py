@@ -35,6 +35,10 @@ SIGNATURES = {
                                       ctypes.c_uint64, c_int_p, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64,
                                       ctypes.c_void_p, ctypes.c_void_p]),
+    "glv_mel_to_audio": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_void_p, ctypes.c_uint64, c_int_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_peak_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
     "glv_peak_reduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,

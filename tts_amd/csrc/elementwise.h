@@ -32,9 +32,7 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
     snat[native_s_index(reg, lane)] = s;
     auto phase_at = [&](int kk) -> cf {
         if (phase_nat) return phase_nat[fr * L.F + kk];
-        const float u = counter_uniform(seed, (uint64_t)((fr + L.frame_origin) * L.F + kk));
-        const float ph = 6.28318530717958647692f * u;
-        return cf{cosf(ph), sinf(ph)};
+        return counter_phasor(seed, (uint64_t)((fr + L.frame_origin) * L.F + kk));
     };
     const cf p = phase_at(k);
     cf ang = cf{p.x * s * inv_n, p.y * s * inv_n};

@@ -478,14 +478,32 @@ GLV_HD int native_bin(int q) {
 GLV_HD int native_spec_index(int reg, int lane) { return ((reg >> 1) * 64 + lane) * 2 + (reg & 1); }
 GLV_HD int native_s_index(int reg, int lane) { return ((reg >> 2) * 64 + lane) * 4 + (reg & 3); }
 
-// uniform [0,1) from a counter (splitmix64 finaliser); the device-side stand-in
-// for librosa's unseeded default_rng when the caller supplies no phase
+// Initial phase drawn on the device: the stand-in for librosa's unseeded default_rng when the
+// caller supplies no phase.  A counter-based generator (two rounds of a 32-bit
+// multiply-xorshift mixer over seed and element index; not numpy's stream) gives u in [0,1),
+// the phasor is (cos, sin)(2 pi u).  On the device the hardware sine / cosine take their
+// argument in revolutions, so u goes in as it is.
+GLV_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
 GLV_HD float counter_uniform(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+    const uint32_t hi = mix32((uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32) ^ 0x9E3779B9u);
+    const uint32_t x = mix32((uint32_t)idx ^ mix32((uint32_t)seed + hi));
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx) {
+    const float u = counter_uniform(seed, idx);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return cf{__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u)};
+#else
+    const float ph = 6.28318530717958647692f * u;
+    return cf{cosf(ph), sinf(ph)};
+#endif
 }
 
 }  // namespace glv

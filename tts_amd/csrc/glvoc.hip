@@ -218,17 +218,31 @@ __global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride,
         ypad[(int64_t)b * ea.L.y_utt_stride + ea.L.n_fft / 2 + n] = y[(int64_t)b * y_stride + n];
 }
 
-__global__ void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
-                                const unsigned char* tail_flag, int blocks_stride, const float* w2,
-                                const float* iwss, const float* iwss_head, const float* iwss_tail,
-                                const float* iwss_small, float* out, int64_t out_stride, int64_t n_begin) {
+__global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
+                                                       const unsigned char* tail_flag, int blocks_stride,
+                                                       const float* w2, const float* iwss,
+                                                       const float* iwss_head, const float* iwss_tail,
+                                                       const float* iwss_small, float* out, int64_t out_stride,
+                                                       int64_t n_begin, unsigned* peak_bits) {
     // samples [n_begin, n_begin + out_stride) of every row; pointers of a time shard are
-    // pre-shifted so that global sample / block indices address them
+    // pre-shifted so that global sample / block indices address them.  With peak_bits the
+    // row maximum of |y| is gathered on the way (one atomic per block, see peak_reduce_kernel).
+    __shared__ float wave_max[4];
     const int b = blockIdx.y;
+    float m = 0.f;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
          n += (int64_t)gridDim.x * blockDim.x)
-        finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head, iwss_tail,
-                        iwss_small, out, out_stride, b, n_begin + n);
+        m = fmaxf(m, finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head,
+                                     iwss_tail, iwss_small, out, out_stride, b, n_begin + n));
+    if (!peak_bits) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(&peak_bits[b], __float_as_uint(m));
+    }
 }
 
 __global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_t y_stride,
@@ -346,6 +360,119 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+// Mel inversion fused with the set-up of the iteration state: for a block of 32 frames the
+// normalised-dB mel is turned into power once (LDS) and multiplied with the inverse basis on
+// the f32 MFMA, 32 bins per wave and step (the same fma chain as gemm_nt_kernel<true,
+// EPI_STORE>, so S is bit-identical).  The magnitudes of 512 bins x 32 frames are collected in
+// LDS, then every wave writes whole native rows: 16-byte stores of S and of the initial
+// angles phase * S / n_fft - what gemm_nt_kernel + init_native_kernel do through a (rows, F)
+// array in HBM.
+//   Wt  inverse basis transposed and zero-padded: [Mp][Fp], Mp a multiple of 16, Fp >= P + 32
+constexpr int kMelWaves = 8;         // waves per block of mel_native_kernel
+constexpr int kMelTileStride = 520;  // floats per frame of the LDS magnitude tile (512 + 8: the
+                                     // accumulator rows 4 apart fall on different banks)
+template <int A>
+__global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea, const float* __restrict__ mel_db,
+                                                         const float* __restrict__ Wt, int M, int Mp, int Fp,
+                                                         float mean, float std_, const cf* phase_nat,
+                                                         uint64_t seed, float inv_n, float* S_native,
+                                                         cf* spec) {
+    extern __shared__ float mel_smem[];
+    const int lds = Mp + 1;
+    float* sa = mel_smem;                          // [32][Mp + 1] mel power of this block's frames
+    float* tile = sa + 32 * lds;               // [32][kMelTileStride] magnitudes of one half
+    float* nyq = tile + 32 * kMelTileStride;   // [32] magnitudes of the Nyquist bin
+    const int P = ea.L.P, F = ea.L.F;
+    const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * Mp; i += 64 * kMelWaves) {
+        const int r = i / Mp, k = i % Mp;
+        float pa = 0.f;
+        if (k < M && row0 + r < rows) {
+            // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
+            const float x = __fadd_rn(__fmul_rn(mel_db[(row0 + r) * M + k], std_), mean);
+            pa = powf(10.0f, __fmul_rn(0.1f, x));
+        }
+        sa[r * lds + k] = pa;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* arow = sa + (lane & 31) * lds + (lane >> 5);
+    auto product = [&](int col0) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* bcol = Wt + (int64_t)(lane >> 5) * Fp + col0 + (lane & 31);
+        // operands of 8 steps are fetched together so their latencies overlap (Mp is a multiple
+        // of 16; the padding rows are zero and add nothing)
+        for (int k0 = 0; k0 < Mp; k0 += 16) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bv[i] = bcol[(int64_t)(k0 + 2 * i) * Fp];
+                av[i] = arow[k0 + 2 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // frame (0..31) of accumulator register `reg` in this lane
+    auto acc_frame = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); };
+    if (wave == kMelWaves - 1) {
+        const f32x16 acc = product(P);
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) nyq[acc_frame(reg)] = acc[reg];
+        }
+    }
+    auto phase_at = [&](int64_t fr, int k) -> cf {
+        if (phase_nat) return phase_nat[fr * F + k];
+        return counter_phasor(seed, (uint64_t)((fr + ea.L.frame_origin) * F + k));
+    };
+    const int low = (lane >> 3) + 8 * (lane & 7);  // this lane's bin modulo 64 on the frequency side
+    for (int h = 0; h < A; ++h) {
+        for (int c = wave; c < 16; c += kMelWaves) {
+            const f32x16 acc = product(512 * h + 32 * c);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) tile[acc_frame(reg) * kMelTileStride + 32 * c + (lane & 31)] = acc[reg];
+        }
+        __syncthreads();
+        for (int f = wave * (32 / kMelWaves); f < (wave + 1) * (32 / kMelWaves); ++f) {
+            const int64_t fr = row0 + f;
+            if (fr >= rows) break;
+            const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
+            if (t >= (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b])) continue;
+            float* snat = S_native + fr * (P + 4);
+            f4* sp = reinterpret_cast<f4*>(spec + fr * P);
+            const float* trow = tile + f * kMelTileStride + low;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float s4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s4[j] = trow[64 * (4 * g + j)];
+                reinterpret_cast<f4*>(snat)[(2 * h + g) * 64 + lane] = f4{s4[0], s4[1], s4[2], s4[3]};
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int ka = 512 * h + low + 64 * (4 * g + 2 * pp);
+                    const cf pa = phase_at(fr, ka), pb = phase_at(fr, ka + 64);
+                    const float sa2 = s4[2 * pp], sb2 = s4[2 * pp + 1];
+                    cf aa = cf{pa.x * sa2 * inv_n, pa.y * sa2 * inv_n};
+                    const cf ab = cf{pb.x * sb2 * inv_n, pb.y * sb2 * inv_n};
+                    if (ka == 0) {
+                        // DC and Nyquist are real and share native bin 0 (c2r ignores their Im)
+                        const cf pn = phase_at(fr, P);
+                        aa.y = pn.x * nyq[f] * inv_n;
+                    }
+                    sp[(4 * h + 2 * g + pp) * 64 + lane] = f4{aa.x, aa.y, ab.x, ab.y};
+                }
+            }
+            if (h == 0 && lane == 0) reinterpret_cast<f4*>(snat + P)[0] = f4{nyq[f], 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
+}
+
 // native spectrum -> natural-order power |D|^2, (rows, F) float32 (librosa's _spectrogram, power=2)
 template <int A>
 __global__ void spec_power_kernel(ElemArgs ea, const cf* spec, float* power) {
@@ -419,6 +546,8 @@ struct glv_plan {
     float* d_iwss_small = nullptr;
     float* d_zeros = nullptr;  // hop zeros followed by hop floats of write-only trash
     float* d_pinv = nullptr;
+    float* d_pinv_t = nullptr;  // transposed, zero-padded to [Mp][Fp] (mel_native_kernel)
+    int Mp = 0, Fp = 0;
     bool have_pinv = false;
     float* d_basis = nullptr;    // (n_mels, F) mel basis, NNLS mode
     float* d_basis_t = nullptr;  // (F, n_mels)
@@ -469,6 +598,8 @@ struct glv_plan {
                         hipStream_t) = nullptr;
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
     void (*launch_power)(const ElemArgs&, const cf*, float*, hipStream_t) = nullptr;
+    hipError_t (*launch_mel_native)(const glv_plan*, const ElemArgs&, const float*, float, float, const cf*,
+                                    uint64_t, float, hipStream_t) = nullptr;
 };
 
 namespace {
@@ -547,8 +678,20 @@ void launch_power_t(const ElemArgs& ea, const cf* spec, float* power, hipStream_
     hipLaunchKernelGGL((spec_power_kernel<A>), dim3(grid_for(total, 256)), dim3(256), 0, st, ea, spec, power);
 }
 
+template <int A>
+hipError_t launch_mel_native_t(const glv_plan* p, const ElemArgs& ea, const float* mel_db, float mean,
+                               float std_, const cf* phase, uint64_t seed, float inv_n, hipStream_t st) {
+    const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
+    const size_t lds = (size_t)(32 * (p->Mp + 1) + 32 * kMelTileStride + 32) * sizeof(float);
+    hipLaunchKernelGGL((mel_native_kernel<A>), dim3((unsigned)((rows + 31) / 32)), dim3(64 * kMelWaves), lds, st, ea,
+                       mel_db, p->d_pinv_t, p->n_mels, p->Mp, p->Fp, mean, std_, phase, seed, inv_n, p->d_S,
+                       p->d_spec);
+    return hipGetLastError();
+}
+
 template <int A, int HB>
 void bind_launchers(glv_plan* p) {
+    p->launch_mel_native = &launch_mel_native_t<A>;
     p->launch_power = &launch_power_t<A>;
     p->launch_engine = &launch_engine_t<A, HB>;
     p->engine_blocks_per_cu = &engine_blocks_per_cu_t<A, HB>;
@@ -570,7 +713,7 @@ void plan_free(glv_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
@@ -778,6 +921,9 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(hipMemcpy(p->d_iwss_small, tab.iwss_small.data(), tab.iwss_small.size() * sizeof(float),
                        hipMemcpyHostToDevice));
     PLAN_TRY(dmalloc(p, &p->d_pinv, (size_t)p->F * n_mels));
+    p->Mp = (n_mels + 15) & ~15;
+    p->Fp = (p->F + 63) & ~63;
+    PLAN_TRY(dmalloc(p, &p->d_pinv_t, (size_t)p->Mp * p->Fp));
     PLAN_TRY(dmalloc(p, &p->d_basis, (size_t)p->F * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_basis_t, (size_t)p->F * n_mels));
     PLAN_TRY(dmalloc(p, &p->d_resid, frames * n_mels));
@@ -867,6 +1013,10 @@ extern "C" int glv_plan_set_inverse_basis(glv_plan* p, const float* pinv_host) {
     if (!p || !pinv_host) return fail(GLV_ERR_INVALID, "null argument");
     DeviceGuard guard(p->device);
     HIP_TRY(hipMemcpy(p->d_pinv, pinv_host, sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
+    std::vector<float> t((size_t)p->Mp * p->Fp, 0.f);
+    for (int f = 0; f < p->F; ++f)
+        for (int m = 0; m < p->n_mels; ++m) t[(size_t)m * p->Fp + f] = pinv_host[(size_t)f * p->n_mels + m];
+    HIP_TRY(hipMemcpy(p->d_pinv_t, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
     p->have_pinv = true;
     return GLV_OK;
 }
@@ -962,11 +1112,18 @@ int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool wi
 
 }  // namespace
 
-extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phase0_dev, uint64_t seed,
-                              const int* n_frames_host, int batch, int frames_stride, int n_iter,
-                              float momentum, float* y_dev, int64_t y_stride, float* sc_curve_dev,
-                              void* stream) {
-    if (!p || !S_dev || !y_dev) return fail(GLV_ERR_INVALID, "null argument");
+namespace {
+
+// where the target magnitudes of a Griffin-Lim call come from
+struct MagnitudeSource {
+    const float* S_dev = nullptr;     // (B, T, F) magnitudes, or
+    const float* mel_db_dev = nullptr;  // (B, T, n_mels) normalised dB mel to invert on the way
+    float mean = 0.f, std_ = 1.f;
+};
+
+int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0_dev, uint64_t seed,
+                    const int* n_frames_host, int batch, int frames_stride, int n_iter, float momentum,
+                    float* y_dev, int64_t y_stride, float* sc_curve_dev, unsigned* peak_bits, void* stream) {
     if (n_iter < 0) return fail(GLV_ERR_INVALID, "n_iter must be >= 0");
     if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
     DeviceGuard guard(p->device);
@@ -995,8 +1152,14 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
     }
     const ElemArgs ea = elem_args(p, batch, frames_stride);
     const float inv_n = 1.0f / (float)p->n_fft;
-    p->launch_init(ea, S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec, st);
-    HIP_TRY(hipGetLastError());
+    if (src.S_dev) {
+        p->launch_init(ea, src.S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec,
+                       st);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(p->launch_mel_native(p, ea, src.mel_db_dev, src.mean, src.std_,
+                                     reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, st));
+    }
 
     // inverse = istft(angles) of the initial phase
     IterArgs a = iter_args(p, frames_stride);
@@ -1043,9 +1206,12 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
         p->ev_valid = true;
     }
     const int last = (p->recompute && !p->traffic_only) ? n_iter % 3 : (n_iter & 1);
-    hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
+    // with the peak gathered on the way every block ends in one atomic on its row's maximum:
+    // few, longer blocks then
+    const unsigned fin_blocks = peak_bits ? std::min<unsigned>(grid_for(y_stride, 256), 32) : grid_for(y_stride, 256);
+    hipLaunchKernelGGL(finalize_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
                        p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
-                       p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0);
+                       p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0, peak_bits);
     HIP_TRY(hipGetLastError());
     if (with_sc) {
         hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
@@ -1054,6 +1220,44 @@ extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phas
         HIP_TRY(hipGetLastError());
     }
     return GLV_OK;
+}
+
+}  // namespace
+
+extern "C" int glv_griffinlim(glv_plan* p, const float* S_dev, const float* phase0_dev, uint64_t seed,
+                              const int* n_frames_host, int batch, int frames_stride, int n_iter,
+                              float momentum, float* y_dev, int64_t y_stride, float* sc_curve_dev,
+                              void* stream) {
+    if (!p || !S_dev || !y_dev) return fail(GLV_ERR_INVALID, "null argument");
+    MagnitudeSource src;
+    src.S_dev = S_dev;
+    return griffinlim_impl(p, src, phase0_dev, seed, n_frames_host, batch, frames_stride, n_iter, momentum,
+                           y_dev, y_stride, sc_curve_dev, nullptr, stream);
+}
+
+extern "C" int glv_mel_to_audio(glv_plan* p, const float* mel_db_dev, float mean, float std_,
+                                const float* phase0_dev, uint64_t seed, const int* n_frames_host, int batch,
+                                int frames_stride, int n_iter, float momentum, float peak_eps, float* y_dev,
+                                int64_t y_stride, float* sc_curve_dev, void* stream) {
+    if (!p || !mel_db_dev || !y_dev || !n_frames_host) return fail(GLV_ERR_INVALID, "null argument");
+    if (!p->have_pinv) return fail(GLV_ERR_STATE, "glv_plan_set_inverse_basis has not been called");
+    if (batch < 1 || batch > p->max_batch) return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool normalise = peak_eps >= 0.f;
+    if (normalise) HIP_TRY(hipMemsetAsync(p->d_peak, 0, sizeof(unsigned) * batch, st));
+    MagnitudeSource src;
+    src.mel_db_dev = mel_db_dev;
+    src.mean = mean;
+    src.std_ = std_;
+    int rc = griffinlim_impl(p, src, phase0_dev, seed, n_frames_host, batch, frames_stride, n_iter, momentum,
+                             y_dev, y_stride, sc_curve_dev, normalise ? p->d_peak : nullptr, stream);
+    if (rc != GLV_OK || !normalise) return rc;
+    // n_samples[b] = hop * (n_frames[b] - 1)
+    std::vector<int> n_samples(batch);
+    for (int b = 0; b < batch; ++b) n_samples[b] = p->hop * (n_frames_host[b] - 1);
+    return glv_peak_scale(p, y_dev, n_samples.data(), batch, y_stride, reinterpret_cast<const float*>(p->d_peak),
+                          peak_eps, stream);
 }
 
 
@@ -1229,7 +1433,7 @@ extern "C" int glv_shard_end(glv_plan* p, float* y_dev, void* stream) {
         hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(n_count, 256), 1), dim3(256), 0, (hipStream_t)stream,
                            ea, p->d_ym[cur] - off, p->d_yt[cur] - off, p->d_flags - p->shard_t0, p->blocks,
                            p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev - n_begin,
-                           n_count, n_begin);
+                           n_count, n_begin, (unsigned*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     p->shard_active = false;
@@ -1387,7 +1591,7 @@ extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_ho
     HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(y_stride, 256), batch), dim3(256), 0, st, ea,
                        p->d_ym[0], p->d_yt[0], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail,
-                       p->d_iwss_small, y_dev, y_stride, (int64_t)0);
+                       p->d_iwss_small, y_dev, y_stride, (int64_t)0, (unsigned*)nullptr);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

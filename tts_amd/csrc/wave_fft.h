@@ -127,6 +127,11 @@ struct Geo {
     static GLV_HD int bin(int q, int lane) {
         return (lane >> 3) + 8 * (lane & 7) + 64 * (q & 7) + 512 * (q >> 3);
     }
+    // inverse of bin(): where bin k < P lives on the frequency side
+    static GLV_HD void locate(int k, int& q, int& lane) {
+        lane = 8 * (k & 7) + ((k >> 3) & 7);
+        q = ((k >> 6) & 7) + 8 * (k >> 9);
+    }
     // first sample (of two) held by (register, lane) on the time side, relative to the frame
     static GLV_HD int sample(int q, int lane) { return ROW * (q & 7) + 2 * A * lane + 2 * (q >> 3); }
     // lane offset (slots) at which a lane finds the mirror partners of its bins inside the

@@ -185,6 +185,32 @@ class GriffinLimPlan:
                                            y_stride, _ptr(sc), _stream_ptr(self.device)))
         return (out, sc) if return_sc else out
 
+    def mel_to_audio(self, mel_db, mean, std, n_frames=None, phase0=None, seed=0, n_iter=60,
+                     momentum=0.99, peak_eps=1e-6, return_sc=False, out=None):
+        """mel_invert + griffinlim + peak_normalize as one library call (the whole of reference
+        vocoder/mel_audio.py:112-132 on a batch) with bit-identical results: the magnitudes never
+        exist as a (B, T, F) array.  ``peak_eps=None`` skips the normalisation."""
+        self._check(mel_db, (self.n_mels,), "mel_db")
+        if mel_db.dim() != 3:
+            raise ValueError("mel_db must be (B, T, n_mels)")
+        b, t, _ = mel_db.shape
+        if phase0 is not None:
+            self._check(phase0, (t, self.n_bins, 2), "phase0")
+        nf, nf_ptr = self._frames(n_frames, b, t)
+        y_stride = self.hop_length * (t - 1)
+        if out is None:
+            out = torch.empty((b, y_stride), dtype=torch.float32, device=self.device)
+        else:
+            self._check(out, (y_stride,), "out")
+        sc = torch.empty((b, n_iter), dtype=torch.float32, device=self.device) \
+            if (return_sc and n_iter > 0) else None
+        _lib.check(self.lib.glv_mel_to_audio(self._handle, _ptr(mel_db), float(mean), float(std),
+                                             _ptr(phase0), int(seed) & (2**64 - 1), nf_ptr, b, t,
+                                             int(n_iter), float(momentum),
+                                             -1.0 if peak_eps is None else float(peak_eps), _ptr(out),
+                                             y_stride, _ptr(sc), _stream_ptr(self.device)))
+        return (out, sc) if return_sc else out
+
     def peak_normalize(self, y, n_samples=None, eps=1e-6):
         """In place audio / (max|audio| + eps) per row (reference vocoder/mel_audio.py:129)."""
         self._check(y, (y.shape[-1],), "y")
@@ -402,15 +428,19 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, 0.0, fmax)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
-    S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
     if init_phase is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
         phase0 = None
     else:
         seed = 0
         phase0 = _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
-    y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)
-    plan.peak_normalize(y)
+    if inversion == "pinv":
+        y = plan.mel_to_audio(mel, mean, std, [frames], phase0=phase0, seed=seed, n_iter=n_iter,
+                              momentum=momentum)
+    else:
+        S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
+        y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)
+        plan.peak_normalize(y)
     audio = y[0]
     if verbose:
         host = audio.cpu().numpy()
@@ -454,13 +484,19 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
     plan = get_plan(n_fft, hop_length, win_length, n_mels, t_max, b, device)
     plan.set_mel_basis(sr, 0.0, fmax)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous()
-    S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
-    res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
-                          return_sc=return_sc)
-    y, sc = res if return_sc else (res, None)
     n_samples = [hop_length * (int(n) - 1) for n in lengths]
-    if normalize:
-        plan.peak_normalize(y, n_samples)
+    if inversion == "pinv":
+        res = plan.mel_to_audio(mel, mean, std, lengths, phase0=phase0, seed=seed, n_iter=n_iter,
+                                momentum=momentum, peak_eps=1e-6 if normalize else None,
+                                return_sc=return_sc)
+        y, sc = res if return_sc else (res, None)
+    else:
+        S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
+        res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
+                              return_sc=return_sc)
+        y, sc = res if return_sc else (res, None)
+        if normalize:
+            plan.peak_normalize(y, n_samples)
     return (y, n_samples, sc) if return_sc else (y, n_samples)
 
 
