@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): the bench lines and rocprofv3 summaries that get copied
+# into profiles/.  Every GPU step has its own time limit; the script stops at the first failure.
+#   scripts/measure_all.sh <tag>
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/measure_$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+run() {  # name, limit, bench args...
+  local name=$1 limit=$2; shift 2
+  timeout -k 10 "$limit" python bench.py "$@" > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "$name failed"; tail -5 "$OUT/$name.err"; exit 1; }
+  echo "$name: $(python -c "import json,sys; d=json.loads(open('$OUT/$name.json').read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['roofline']['kernel_ms_per_launch'], 'ms/launch frac', d['roofline']['frac'])")"
+}
+run bench_default 400
+run bench_unfused 200 --no-cpu --unfused
+run bench_ljspeech_lengths 200 --no-cpu --lengths ljspeech
+run bench_n2048_t865 200 --no-cpu --n-fft 2048 --frames 865
+run bench_b4096 300 --no-cpu --batch 4096 --steps 3 --warmup 1
+run bench_b8 200 --no-cpu --batch 8
+run bench_single_ref_utterance 200 --no-cpu --batch 1 --n-fft 2048 --frames 865 --steps 50 --warmup 5
+run ablation_traffic_only 200 --no-cpu --traffic-only
+run ablation_compute_only 200 --no-cpu --alias-utts
+run ablation_recompute 200 --no-cpu --recompute 1
+run ablation_n2048_traffic_only 200 --no-cpu --n-fft 2048 --frames 865 --traffic-only
+run ablation_n2048_compute_only 200 --no-cpu --n-fft 2048 --frames 865 --alias-utts
+run ablation_no_graph 200 --no-cpu --no-graph
+scripts/profile_gpu.sh "$TAG" > "$OUT/profile.log" 2>&1 || { echo "profile failed"; tail -5 "$OUT/profile.log"; exit 1; }
+scripts/profile_gpu.sh "${TAG}_n2048" --n-fft 2048 --frames 865 > "$OUT/profile_n2048.log" 2>&1 || { echo "profile n2048 failed"; tail -5 "$OUT/profile_n2048.log"; exit 1; }
+echo done

@@ -21,7 +21,7 @@ def find(outdir, sub, suffix):
 
 
 def short(name):
-    for key in ("gl_engine_kernel", "gemm_nt_kernel", "root_kernel", "mel_invert_kernel", "init_native_kernel", "finalize_kernel",
+    for key in ("gl_engine_kernel", "gemm_nt_kernel", "mel_native_kernel", "root_kernel", "init_native_kernel", "finalize_kernel",
                 "peak_reduce_kernel", "peak_scale_kernel", "sc_reduce_kernel", "spec_convert_kernel",
                 "pad_signal_kernel"):
         if key in name:

@@ -500,3 +500,30 @@ def test_single_call_equals_three_calls(voc, n_fft, hop):
             raw1 = plan.mel_to_audio(md, MEAN, STD, lens, phase0=phase0, seed=seed, n_iter=5, peak_eps=None)
             assert torch.equal(raw1, raw3)
         plan.close()
+
+
+def test_long_form_single_utterance(voc, O):
+    """A 10-minute mel (51 680 frames, n_fft 1024) on one GPU: size-independent properties, and
+    the middle of the waveform against the oracle run on a window of frames around it (frames
+    further than the iteration count times the overlap cannot influence it)."""
+    frames, n_fft, hop, k = 51680, 1024, 256, 4
+    mel = np.concatenate([synthetic_mel(300 + i, 430) for i in range(121)])[:frames]
+    assert mel.shape == (frames, 80)
+    rng = np.random.default_rng(8)
+    phase = np.exp(2j * np.pi * rng.random((n_fft // 2 + 1, frames))).astype(np.complex64)
+    plan = voc.get_plan(n_fft, hop, n_fft, 80, frames, 1)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    p0 = dev(np.ascontiguousarray(np.stack([phase.T.real, phase.T.imag], -1)[None], dtype=np.float32))
+    y, sc = plan.mel_to_audio(dev(mel[None]), MEAN, STD, [frames], phase0=p0, n_iter=k, peak_eps=None,
+                              return_sc=True)
+    y, sc = y[0].cpu().numpy(), sc[0].cpu().numpy()
+    assert y.shape == (hop * (frames - 1),) and np.all(np.isfinite(y))
+    assert np.all(np.diff(sc) < 0)
+    # window of frames [t0, t1) -> oracle; compare the centre where both see the same neighbours
+    t0, t1 = 25000, 25200
+    S = O.mel_invert(mel[t0:t1], MEAN, STD, n_fft=n_fft)
+    ref = O.griffinlim(S, n_iter=k, hop_length=hop, win_length=n_fft, n_fft=n_fft, init_phase=phase[:, t0:t1])
+    margin = (k + 2) * (n_fft // hop)          # frames whose samples may differ at either end
+    a, b = margin * hop, (t1 - t0 - 1 - margin) * hop
+    got = y[t0 * hop + a: t0 * hop + b]
+    assert rel_l2(got, ref[a:b]) < 1e-3
