@@ -2,7 +2,7 @@
 tts_amd.vocoder.GriffinLimPlan), against the CPU oracle on identical inputs and
 an identical initial phase.
 
-Tolerances (BASELINE north star): linear spectrogram after mel inversion within
+Tolerances: linear spectrogram after mel inversion within
 1e-4 relative L2; waveform after k iterations within 1e-3 relative L2 in fp32;
 per-iteration spectral-convergence curve within 1 %.  Fast Griffin-Lim with
 momentum 0.99 amplifies fp32 rounding differences exponentially in k (the
@@ -215,7 +215,7 @@ def test_drop_in_on_reference_fixture(voc, O, lj001):
 
 
 def test_full_size_batch_properties(voc):
-    """BASELINE batch shape (64 utterances x 430 frames, n_fft=1024, 60 iterations):
+    """The benchmark batch shape (64 utterances x 430 frames, n_fft=1024, 60 iterations):
     size-independent properties instead of an oracle run."""
     b, frames, n_fft, hop = 64, 430, 1024, 256
     mels = np.stack([synthetic_mel(1234 + i, frames) for i in range(b)])

@@ -101,6 +101,41 @@ struct IterArgs {
     int raw_in;               // y_in holds the padded signal itself (glv_stft)
 };
 
+// Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
+// again before the whole working set has passed through the caches, so the accesses can be
+// marked non-temporal (GLV_STREAM_NT bit 0: loads, bit 1: stores); plain accesses otherwise.
+#ifndef GLV_STREAM_NT
+#define GLV_STREAM_NT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && GLV_STREAM_NT
+typedef float glv_v2f __attribute__((ext_vector_type(2)));
+typedef float glv_v4f __attribute__((ext_vector_type(4)));
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && (GLV_STREAM_NT & 1)
+__device__ __forceinline__ cf ld_stream(const cf* p) {
+    const glv_v2f v = __builtin_nontemporal_load(reinterpret_cast<const glv_v2f*>(p));
+    return cf{v.x, v.y};
+}
+__device__ __forceinline__ f4 ld_stream(const f4* p) {
+    const glv_v4f v = __builtin_nontemporal_load(reinterpret_cast<const glv_v4f*>(p));
+    return f4{v.x, v.y, v.z, v.w};
+}
+#else
+GLV_HD cf ld_stream(const cf* p) { return *p; }
+GLV_HD f4 ld_stream(const f4* p) { return *p; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && (GLV_STREAM_NT & 2)
+__device__ __forceinline__ void st_stream(cf* p, cf v) {
+    __builtin_nontemporal_store(glv_v2f{v.x, v.y}, reinterpret_cast<glv_v2f*>(p));
+}
+__device__ __forceinline__ void st_stream(f4* p, f4 v) {
+    __builtin_nontemporal_store(glv_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<glv_v4f*>(p));
+}
+#else
+GLV_HD void st_stream(cf* p, cf v) { *p = v; }
+GLV_HD void st_stream(f4* p, f4 v) { *p = v; }
+#endif
+
 GLV_HD float rcp_refined(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r = __builtin_amdgcn_rcpf(x);
@@ -182,9 +217,9 @@ struct Engine {
     // a lane's share of row i of a block: 2A contiguous floats -> one register per sub-sequence
     GLV_HD void load_row(const float* p, int i, cf* dst) const {
         if (A == 1) {
-            dst[i] = *reinterpret_cast<const cf*>(p + ROW * i + 2 * lane);
+            dst[i] = ld_stream(reinterpret_cast<const cf*>(p + ROW * i + 2 * lane));
         } else {
-            const f4 q = *reinterpret_cast<const f4*>(p + ROW * i + 4 * lane);
+            const f4 q = ld_stream(reinterpret_cast<const f4*>(p + ROW * i + 4 * lane));
             dst[i] = cf{q.x, q.y};
             dst[i + HB * (A - 1)] = cf{q.z, q.w};
         }
@@ -259,7 +294,7 @@ struct Engine {
         const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
-            const f4 sq = reinterpret_cast<const f4*>(sf)[q * 64 + lane];
+            const f4 sq = ld_stream(reinterpret_cast<const f4*>(sf) + q * 64 + lane);
             s_n[4 * q] = sq.x;
             s_n[4 * q + 1] = sq.y;
             s_n[4 * q + 2] = sq.z;
@@ -274,10 +309,10 @@ struct Engine {
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
             if (A == 1) {
-                *reinterpret_cast<cf*>(p + ROW * i + 2 * lane) = src[row0 + i];
+                st_stream(reinterpret_cast<cf*>(p + ROW * i + 2 * lane), src[row0 + i]);
             } else {
                 const cf lo = src[row0 + i], hi = src[row0 + i + 8 * (A - 1)];
-                *reinterpret_cast<f4*>(p + ROW * i + 4 * lane) = f4{lo.x, lo.y, hi.x, hi.y};
+                st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
             }
         }
     }
@@ -345,13 +380,13 @@ struct Engine {
         f4* sp = reinterpret_cast<f4*>(spec_frame(a, t));
 #pragma unroll
         for (int pq = q0 / 2; pq < (q0 + nq) / 2; ++pq)
-            sp[pq * 64 + lane] = f4{v[2 * pq].x, v[2 * pq].y, v[2 * pq + 1].x, v[2 * pq + 1].y};
+            st_stream(sp + pq * 64 + lane, f4{v[2 * pq].x, v[2 * pq].y, v[2 * pq + 1].x, v[2 * pq + 1].y});
     }
     GLV_HD void load_spec(const IterArgs& a, int t, cf (&dst)[E], int q0 = 0, int nq = E) const {
         const f4* sp = reinterpret_cast<const f4*>(spec_frame(a, t));
 #pragma unroll
         for (int pq = q0 / 2; pq < (q0 + nq) / 2; ++pq) {
-            const f4 q = sp[pq * 64 + lane];
+            const f4 q = ld_stream(sp + pq * 64 + lane);
             dst[2 * pq] = cf{q.x, q.y};
             dst[2 * pq + 1] = cf{q.z, q.w};
         }

@@ -52,7 +52,10 @@ extern "C" int glv_version(void) { return 100; }
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+#ifndef GLV_WAVES_PER_BLOCK
+#define GLV_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 
 __device__ __forceinline__ void wave_sync() {
     // Orders this wave's LDS writes before its later LDS reads (other lanes' data).

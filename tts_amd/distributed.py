@@ -123,7 +123,7 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
                              n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, seed=0, group=None,
                              device=None, normalize=True):
     """Long-form synthesis of ONE utterance sharded along time over the ranks of `group`
-    (BASELINE config 4: a 10-minute mel over 8 GPUs).
+    (for example a 10-minute mel over 8 GPUs).
 
     `mel_db` is the whole (T, n_mels) mel, present on every rank; rank r keeps frames
     `split_frames(T, world)[r]`, inverts and iterates only those, and swaps n_fft - hop
