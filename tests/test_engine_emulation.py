@@ -37,7 +37,7 @@ def emu_griffinlim(emu, s_btf, ph_btf2, lens, n_fft, hop, win, n_iter, fpr, mome
 SHAPES = [(1024, 256, 1024, 23, 7), (1024, 256, 1024, 23, 100), (2048, 256, 2048, 26, 9),
           (2048, 512, 2048, 17, 5), (1024, 512, 1024, 9, 3), (1024, 128, 1024, 30, 9),
           (2048, 1024, 2048, 12, 4), (1024, 256, 800, 15, 4), (1024, 256, 1024, 2, 8),
-          (1024, 256, 1024, 5, 2)]
+          (1024, 256, 1024, 5, 2), (2048, 256, 2048, 3, 8), (2048, 512, 2048, 2, 4), (2048, 256, 1200, 6, 7)]
 
 
 @pytest.mark.parametrize("n_fft,hop,win,frames,fpr", SHAPES)

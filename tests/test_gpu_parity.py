@@ -125,11 +125,12 @@ def test_fixture_60_iterations(voc, O, lj001, n_fft, frames):
     plan.close()
 
 
-def test_ragged_batch_equals_single_runs(voc, O):
-    """Utterances of different lengths in one batch: every row is bit-identical to the
-    same utterance processed alone, and rows are zero past their own length."""
-    n_fft, hop = 1024, 256
-    lens = [33, 7, 64, 20]
+@pytest.mark.parametrize("n_fft,hop,lens", [(1024, 256, [33, 7, 64, 20]), (2048, 256, [40, 3, 2, 17, 6]),
+                                            (2048, 1024, [9, 2, 5]), (1024, 128, [4, 30, 2])])
+def test_ragged_batch_equals_single_runs(voc, O, n_fft, hop, lens):
+    """Utterances of different lengths in one batch - down to two frames, shorter than the
+    overlap - are bit-identical to the same utterance processed alone, zero past their own
+    length, and match the oracle."""
     f = n_fft // 2 + 1
     t_max = max(lens)
     rng = np.random.default_rng(5)
