@@ -210,6 +210,10 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 /*
  * Tuning and measurement hooks (no counterpart in the reference).
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
+ *                        "single_frame" (-1 automatic / 0 / 1: give every frame a wavefront of its
+ *                        own - R partial-sum buffers instead of a running sum - which is what a
+ *                        batch with fewer frames than the device has wave slots needs; automatic
+ *                        only while "frames_per_run" is 0),
  *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
  *                        "timing" (0/1: bracket the iteration loop with hipEvents),
  *                        "recompute" (0/1: iterate without the spectrum state in memory - the

@@ -28,6 +28,35 @@ void emu_launch(const IterArgs& a) {
     for (int ri = 0; ri < a.n_runs; ++ri) {
         const RunDesc run = a.runs[ri];
         for (int l = 0; l < 64; ++l) e[l].init(a, a.tables, l, run);
+        if (MODE == MODE_ITER1 || MODE == MODE_ISTFT1) {
+            // one frame per wave: no sliding window, no running sum
+            const int t = run.t_begin;
+            if (MODE == MODE_ITER1) {
+                for (int l = 0; l < 64; ++l) e[l].template ph0_single<true>(a, t, b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].template ph3_update<SC, 0, false>(a, t, b0.data());
+            } else {
+                for (int l = 0; l < 64; ++l) e[l].ph3_load(a, t);
+            }
+            for (int l = 0; l < 64; ++l) e[l].ph3_write(b1.data());
+            for (int l = 0; l < 64; ++l) e[l].ph4(b1.data(), b0.data());
+            for (int l = 0; l < 64; ++l) e[l].ph5_read(b0.data());
+            for (int l = 0; l < 64; ++l) e[l].ph5_write(b1.data());
+            for (int l = 0; l < 64; ++l) e[l].ph6_single(a, t, b1.data());
+            if (SC && a.sc_partial) {
+                float num = 0.f, den = 0.f;
+                for (int l = 0; l < 64; ++l) {
+                    num += e[l].sc_num;
+                    den += e[l].sc_den;
+                }
+                a.sc_partial[2 * ri] = num;
+                a.sc_partial[2 * ri + 1] = den;
+            }
+            continue;
+        }
         constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
         constexpr int kRcArg = MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0);
         if (MODE != MODE_ISTFT)
@@ -155,6 +184,60 @@ struct Emu {
                                 tab.iwss_small.data(), y, y_stride, b, n);
     }
 
+    // one frame per wave: every frame is its own run, R partial-sum buffers per generation
+    int griffinlim_single(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
+                          float* y, int64_t y_stride, float* sc) {
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < nf[b]; ++t)
+                for (int q = 0; q < P; ++q)
+                    init_native_element<A>(L, S, reinterpret_cast<const cf*>(phase0), seed, a.inv_n,
+                                           S_native.data(), spec.data(), b, t, q);
+        std::vector<RunDesc> single;
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < nf[b]; ++t) single.push_back(RunDesc{b, t, t + 1, nf[b]});
+        a.runs = single.data();
+        a.n_runs = (int)single.size();
+        const int64_t stride = (int64_t)batch * blocks * H;
+        std::vector<float> parts[2];
+        // garbage, not zeros: whatever a reader may use has been written by the launch before
+        for (auto& p : parts) p.assign((size_t)R * stride, 1.0e30f);
+        a.part_stride = stride;
+        a.cmom = momentum / (1.0f + momentum);
+        a.raw_in = 0;
+        std::vector<float> scp(2 * single.size(), 0.f);
+        a.part_out = parts[0].data();
+        emu_launch<A, HB, MODE_ISTFT1, false>(a);
+        int cur = 0;
+        for (int k = 0; k < n_iter; ++k) {
+            a.has_prev = k > 0;
+            a.sc_partial = sc ? scp.data() : nullptr;
+            a.part_in = parts[cur].data();
+            a.part_out = parts[cur ^ 1].data();
+            if (sc)
+                emu_launch<A, HB, MODE_ITER1, true>(a);
+            else
+                emu_launch<A, HB, MODE_ITER1, false>(a);
+            cur ^= 1;
+            if (sc)
+                for (int b = 0; b < batch; ++b) {
+                    double num = 0, den = 0;
+                    for (size_t r = 0; r < single.size(); ++r)
+                        if (single[r].utt == b) {
+                            num += scp[2 * r];
+                            den += scp[2 * r + 1];
+                        }
+                    sc[(size_t)b * n_iter + k] = (float)std::sqrt(num / den);
+                }
+        }
+        for (int b = 0; b < batch; ++b)
+            for (int64_t n = 0; n < y_stride; ++n)
+                finalize_sample_parts(L, parts[cur].data(), stride, tab.iwss.data(), tab.iwss_head.data(),
+                                      tab.iwss_tail.data(), tab.iwss_small.data(), y, y_stride, b, n);
+        a.runs = runs.data();
+        a.n_runs = (int)runs.size();
+        return 0;
+    }
+
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
                    float* y, int64_t y_stride, float* sc, bool recompute) {
         for (int b = 0; b < batch; ++b)
@@ -257,9 +340,12 @@ extern "C" {
 int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const float* phase0,
                    uint64_t seed, const int* n_frames, int batch, int frames_stride, int n_iter,
                    float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc, int recompute) {
+    // recompute: 0 = run-based iteration, 1 = its recompute-the-previous-spectrum variant,
+    //            2 = one frame per wave
     return dispatch(n_fft, hop, [&](auto* tag) {
         using E = std::remove_pointer_t<decltype(tag)>;
         E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
+        if (recompute == 2) return e.griffinlim_single(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
         return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, recompute != 0);
     });
 }

@@ -170,3 +170,32 @@ def test_device_phase_generator_statistics(emu):
     assert abs(corr(a, draw(1 << 32, 0))) < 0.01
     # the phasor sum of n random phases is O(sqrt(n))
     assert abs(np.exp(2j * np.pi * a).sum()) < 5 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("n_fft,hop,win,lens", [(1024, 256, 1024, [23, 2, 9]), (2048, 256, 2048, [26, 3]),
+                                                (2048, 512, 1200, [12]), (1024, 128, 1024, [30, 5]),
+                                                (1024, 512, 1024, [7]), (2048, 1024, 2048, [6, 2])])
+def test_one_frame_per_wave_mode_matches_oracle(emu, n_fft, hop, win, lens):
+    """The small-batch form of the iteration (every frame its own wave, R partial-sum buffers
+    instead of a running sum) is the same algorithm: ragged lengths, edge blocks, signed
+    magnitudes, and buffers that start out holding garbage."""
+    f = n_fft // 2 + 1
+    t_max = max(lens)
+    rng = np.random.default_rng(31 + t_max)
+    s = np.zeros((len(lens), t_max, f), np.float32)
+    p = np.zeros((len(lens), t_max, f, 2), np.float32)
+    for b, t in enumerate(lens):
+        s[b, :t] = rng.standard_normal((t, f)) ** 2
+        s[b, :t, ::7] *= -0.3
+        ang = 2 * np.pi * rng.random((t, f))
+        p[b, :t, :, 0], p[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+    for k in (0, 4):
+        y, sc = emu_griffinlim(emu, s, p, lens, n_fft, hop, win, k, 1, recompute=2)
+        for b, t in enumerate(lens):
+            n = hop * (t - 1)
+            ref, sc_ref = O.griffinlim(np.ascontiguousarray(s[b, :t].T), n_iter=k, hop_length=hop, win_length=win,
+                                       n_fft=n_fft, init_phase=from_btf2(p[b, :t]), return_sc=True)
+            assert rel_l2(y[b, :n], ref) < 5e-6
+            assert np.all(y[b, n:] == 0)
+            if k:
+                assert np.max(np.abs(sc[b] - sc_ref) / sc_ref) < 1e-5

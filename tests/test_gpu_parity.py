@@ -528,3 +528,51 @@ def test_long_form_single_utterance(voc, O):
     a, b = margin * hop, (t1 - t0 - 1 - margin) * hop
     got = y[t0 * hop + a: t0 * hop + b]
     assert rel_l2(got, ref[a:b]) < 1e-3
+
+
+@pytest.mark.parametrize("n_fft,hop,win,lens", [(1024, 256, 1024, [33, 2, 64, 7]), (2048, 256, 2048, [40, 3, 17]),
+                                                (2048, 512, 1200, [21, 6]), (1024, 128, 1024, [30, 5]),
+                                                (2048, 1024, 2048, [9, 2]), (1024, 512, 800, [12, 3])])
+def test_one_frame_per_wave_mode(voc, O, n_fft, hop, win, lens):
+    """The small-batch form of the iteration (option single_frame: every frame a wavefront of
+    its own, partial-sum buffers instead of a running sum) against the oracle and against the
+    run-based form, waveform and convergence curve, on ragged batches down to two frames."""
+    f = n_fft // 2 + 1
+    t_max = max(lens)
+    rng = np.random.default_rng(17 + t_max)
+    s = np.zeros((len(lens), t_max, f), np.float32)
+    p = np.zeros((len(lens), t_max, f, 2), np.float32)
+    for b, t in enumerate(lens):
+        s[b, :t] = rng.standard_normal((t, f)) ** 2
+        s[b, :t, ::7] *= -0.3
+        ang = 2 * np.pi * rng.random((t, f))
+        p[b, :t, :, 0], p[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, win, 80, t_max, len(lens))
+    out = {}
+    for mode in (1, 0):
+        plan.set_option("single_frame", mode)
+        for graph in (1, 0):
+            plan.set_option("use_graph", graph)
+            y, sc = plan.griffinlim(dev(s), lens, phase0=dev(p), n_iter=6, return_sc=True)
+            out[mode, graph] = (y.cpu().numpy(), sc.cpu().numpy())
+        assert np.array_equal(out[mode, 0][0], out[mode, 1][0])
+    y1, sc1 = out[1, 1]
+    y0, sc0 = out[0, 1]
+    for b, t in enumerate(lens):
+        n = hop * (t - 1)
+        ref, sc_ref = O.griffinlim(np.ascontiguousarray(s[b, :t].T), n_iter=6, hop_length=hop, win_length=win,
+                                   n_fft=n_fft, init_phase=from_btf2(p[b, :t]), return_sc=True)
+        assert rel_l2(y1[b, :n], ref) < 1e-4
+        assert rel_l2(y1[b, :n], y0[b, :n]) < 1e-4
+        assert np.all(y1[b, n:] == 0)
+        assert np.max(np.abs(sc1[b] - sc_ref) / sc_ref) < 1e-4
+    # a second call with other lengths reuses the buffers (they hold the previous call's sums)
+    lens2 = [max(2, t // 2) for t in lens]
+    plan.set_option("single_frame", 1)
+    y2 = plan.griffinlim(dev(s), lens2, phase0=dev(p), n_iter=2).cpu().numpy()
+    for b, t in enumerate(lens2):
+        n = hop * (t - 1)
+        ref = O.griffinlim(np.ascontiguousarray(s[b, :t].T), n_iter=2, hop_length=hop, win_length=win,
+                           n_fft=n_fft, init_phase=from_btf2(p[b, :t]))
+        assert rel_l2(y2[b, :n], ref) < 1e-4
+    plan.close()

@@ -95,4 +95,26 @@ GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const flo
     return fabsf(val);
 }
 
+// the same for the one-frame-per-wave modes: the sample is the sum of the R partial-sum buffers
+// (frames ascending), see Engine::load_frame_from_parts
+GLV_HD float finalize_sample_parts(const LayoutArgs& L, const float* parts, int64_t part_stride,
+                                   const float* iwss, const float* iwss_head, const float* iwss_tail,
+                                   const float* iwss_small, float* out, int64_t out_stride, int b, int64_t n) {
+    const int T = L.n_frames[b];
+    const int64_t len = (int64_t)L.hop * (T - 1);
+    float val = 0.f;
+    if (n < len) {
+        const int64_t p = n + L.n_fft / 2;
+        const int j = (int)(p / L.hop), s = (int)(p % L.hop);
+        const int64_t at = (int64_t)b * L.y_utt_stride + p;
+        for (int d = L.R - 1; d >= 0; --d) {
+            const int tc = j - d;
+            if (tc >= 0 && tc < T) val += parts[(int64_t)(tc & (L.R - 1)) * part_stride + at];
+        }
+        val *= iwss_row(iwss, iwss_head, iwss_tail, iwss_small, L.hop, L.R, T, j)[s];
+    }
+    out[(int64_t)b * out_stride + n] = val;
+    return fabsf(val);
+}
+
 }  // namespace glv

@@ -45,8 +45,16 @@
 // every load of a phase to its top and hold all results in registers at once).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GLV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the same for memory operations at every level of the compiler: nothing that touches memory
+// moves across (no instruction is emitted)
+#define GLV_MEM_FENCE() asm volatile("" ::: "memory")
+// ... and with a value that has to be in its register by then (pins the arithmetic producing
+// it, and the loads that feeds, in front of the fence)
+#define GLV_PIN(x) asm volatile("" : "+v"(x)::"memory")
 #else
 #define GLV_SCHED_FENCE() ((void)0)
+#define GLV_MEM_FENCE() ((void)0)
+#define GLV_PIN(x) ((void)0)
 #endif
 namespace glv {
 
@@ -63,13 +71,18 @@ struct RunDesc {
 // MODE_ITER_RC / MODE_ITER_RC_FIRST: the iteration without the spectrum state in HBM - the
 // previous rebuilt spectrum (the momentum term) is recomputed from the previous signal,
 // which costs one more forward FFT per frame and saves reading and writing 8P bytes.
+// MODE_ITER1 / MODE_ISTFT1: one frame per wave, for batches too small to fill the device with
+// runs.  There is no running sum: a frame's windowed output goes, as R whole blocks, to
+// partial-sum buffer (t mod R), and a reader adds the R buffers (see load_frame_from_parts).
 enum Mode {
     MODE_ITER = 0,
     MODE_ISTFT = 1,
     MODE_STFT = 2,
     MODE_TRAFFIC = 3,
     MODE_ITER_RC = 4,
-    MODE_ITER_RC_FIRST = 5
+    MODE_ITER_RC_FIRST = 5,
+    MODE_ITER1 = 6,
+    MODE_ISTFT1 = 7
 };
 
 struct IterArgs {
@@ -83,6 +96,9 @@ struct IterArgs {
     const float* y_prev_tail;
     float* y_out;
     float* y_out_tail;
+    const float* part_in;     // R partial-sum buffers of the previous iteration (MODE_ITER1), laid
+    float* part_out;          //   out like y_in, part_stride floats apart; and those being written
+    int64_t part_stride;
     int64_t spec_utt_stride;  // cf units
     int64_t s_utt_stride;     // floats
     int64_t y_utt_stride;     // floats
@@ -104,6 +120,9 @@ struct IterArgs {
 // Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
 // again before the whole working set has passed through the caches, so the accesses can be
 // marked non-temporal (GLV_STREAM_NT bit 0: loads, bit 1: stores); plain accesses otherwise.
+#ifndef GLV_PARTS_DEPTH
+#define GLV_PARTS_DEPTH 2
+#endif
 #ifndef GLV_STREAM_NT
 #define GLV_STREAM_NT 0
 #endif
@@ -397,7 +416,7 @@ struct Engine {
     // angles /= |angles| + tiny; angles *= S; tprev = rebuilt.
     // RC = 0: tprev lives in `spec` (read, then overwritten with rebuilt); 1: tprev was just
     // recomputed into tp_n and nothing is stored; 2: first iteration of that scheme (no tprev).
-    template <bool SC, int RC = 0>
+    template <bool SC, int RC = 0, bool PREFETCH_NEXT = true>
     GLV_HD void ph3_update(const IterArgs& a, int t, const cf* r) {
         // first iteration: no momentum term (tp_n then holds the initial angles, times zero)
         const float cmom = (RC == 2 || (RC == 0 && !a.has_prev)) ? 0.0f : a.cmom;
@@ -434,6 +453,7 @@ struct Engine {
             }
             if (CH < E) GLV_SCHED_FENCE();
         }
+        if (!PREFETCH_NEXT) return;
         if (RC == 0)
             prefetch_spec(a, t + 1);
         else
@@ -492,6 +512,103 @@ struct Engine {
 #pragma unroll
             for (int r = 8 - HB; r < 8; ++r) acc[r + 8 * s2] = cf{0.f, 0.f};
     }
+    // ---- one frame per wave (MODE_ITER1 / MODE_ISTFT1) ----
+    // Frame tc writes its windowed output, R whole blocks tc .. tc+R-1, to partial-sum buffer
+    // (tc mod R): no two frames write the same place.  Block j of the signal is then the sum
+    // over the frames j-R+1 .. j that exist, each found in its own buffer, added in ascending
+    // frame order like the running sum of the run-based modes (and like librosa's overlap-add).
+    GLV_HD void load_frame_from_parts(const IterArgs& a, int t) {
+        const int64_t utt_off = (int64_t)run.utt * a.y_utt_stride;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int j = t + q;
+            const bool valid = block_valid(j);
+            const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
+            cf sum[HV];
+#pragma unroll
+            for (int k = 0; k < HV; ++k) sum[k] = cf{0.f, 0.f};
+#pragma unroll
+            for (int d = R - 1; d >= 0; --d) {
+                const int tc = j - d;
+                const bool ok = valid && tc >= 0 && tc < run.n_frames;
+                const float* p = ok ? a.part_in + (int64_t)(tc & (R - 1)) * a.part_stride + utt_off + (int64_t)j * H
+                                    : a.zeros;
+                cf part[HV];
+#pragma unroll
+                for (int i = 0; i < HB; ++i) load_row(p, i, part);
+#pragma unroll
+                for (int k = 0; k < HV; ++k) sum[k] = sum[k] + part[k];
+            }
+            cf w[HV];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) load_row(pw, i, w);
+#pragma unroll
+            for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    const int k = i + HB * s2;
+                    raw[q * HB + i + 8 * s2] = cf{sum[k].x * w[k].x, sum[k].y * w[k].y};
+                }
+            // one block's R + 1 loads at a time: with all R * R in flight the register
+            // allocator spills and every load is waited for singly
+            // Keep the loads of GLV_PARTS_DEPTH + 1 blocks in flight, no more: with all R * R
+            // outstanding the register allocator spills and every load ends up waited for singly.
+            if (A == 2 && q >= GLV_PARTS_DEPTH) {
+                pin_block(q - GLV_PARTS_DEPTH);
+                GLV_SCHED_FENCE();
+            }
+        }
+    }
+    // the sums of block q have to be in their registers here (and no memory operation moves across)
+    GLV_HD void pin_block(int q) {
+#pragma unroll
+        for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                GLV_PIN(raw[q * HB + i + 8 * s2].x);
+                GLV_PIN(raw[q * HB + i + 8 * s2].y);
+            }
+    }
+    // phase 0 of a single-frame wave: the whole window is fetched, nothing slides
+    template <bool WITH_SPEC>
+    GLV_HD void ph0_single(const IterArgs& a, int t, cf* w) {
+        load_frame_from_parts(a, t);
+        // the previous spectrum and the magnitudes are not needed before phase 3: their latency
+        // hides behind the forward transform
+        if (WITH_SPEC) prefetch_spec(a, t);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const cf wn = tab.win[r * 64 + lane];
+            v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
+        }
+        F::fwd_a(v, tab, w, lane);
+    }
+    // phase 6 of a single-frame wave: last inverse pass, window, the frame's R blocks go out
+    GLV_HD void ph6_single(const IterArgs& a, int t, const cf* r) {
+        F::inv_a(v, tab, r, lane);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const cf wn = tab.win[q * 64 + lane];
+            v[q] = cf{v[q].x * wn.x, v[q].y * wn.y};
+        }
+        float* base = a.part_out + (int64_t)(t & (R - 1)) * a.part_stride + (int64_t)run.utt * a.y_utt_stride;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int j = t + q;
+            float* p = block_valid(j) ? base + (int64_t)j * H : a.trash;
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int row = q * HB + i;
+                if (A == 1) {
+                    st_stream(reinterpret_cast<cf*>(p + ROW * i + 2 * lane), v[row]);
+                } else {
+                    const cf lo = v[row], hi = v[row + 8 * (A - 1)];
+                    st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
+                }
+            }
+        }
+    }
+
     // what is left after the last frame belongs to blocks t_end .. t_end+R-2
     GLV_HD void flush_tails(const IterArgs& a) {
 #pragma unroll

@@ -98,7 +98,37 @@ gl_engine_kernel(IterArgs a) {
     Eng e;
     e.init(a, tables, lane, rd);
     constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
-    if (MODE != MODE_ISTFT) {
+    constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1;
+    if (kSingle) {
+        // one frame per wave: the run is the frame
+        const int t = e.run.t_begin;
+        if (MODE == MODE_ITER1) {
+            e.template ph0_single<true>(a, t, xb);
+            wave_sync();
+            e.ph1_read(xb);
+            wave_sync();
+            e.ph1_write(xb);
+            wave_sync();
+            e.ph2_read(xb);
+            wave_sync();
+            e.ph2_write(xb);
+            wave_sync();
+            e.template ph3_update<SC, 0, false>(a, t, xb);
+        } else {
+            e.ph3_load(a, t);
+        }
+        wave_sync();
+        e.ph3_write(xb);
+        wave_sync();
+        e.ph4(xb, xb);
+        wave_sync();
+        e.ph5_read(xb);
+        wave_sync();
+        e.ph5_write(xb);
+        wave_sync();
+        e.ph6_single(a, t, xb);
+    }
+    if (!kSingle && MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
     }
@@ -108,7 +138,7 @@ gl_engine_kernel(IterArgs a) {
     }
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     if (kRc) e.prefetch_s(a, e.run.t_begin);
-    for (int t = e.run.t_begin; t < e.run.t_end; ++t) {
+    for (int t = e.run.t_begin; !kSingle && t < e.run.t_end; ++t) {
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
             continue;
@@ -160,7 +190,7 @@ gl_engine_kernel(IterArgs a) {
         e.ph6(a, t, xb);
         wave_sync();
     }
-    if (MODE != MODE_STFT) e.flush_tails(a);
+    if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
     if (SC) {
         float num = e.sc_num, den = e.sc_den;
 #pragma unroll
@@ -237,6 +267,29 @@ __global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float*
          n += (int64_t)gridDim.x * blockDim.x)
         m = fmaxf(m, finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head,
                                      iwss_tail, iwss_small, out, out_stride, b, n_begin + n));
+    if (!peak_bits) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(&peak_bits[b], __float_as_uint(m));
+    }
+}
+
+// finalize_kernel for the one-frame-per-wave modes: the sample is the sum of R partial buffers
+__global__ __launch_bounds__(256) void finalize_parts_kernel(ElemArgs ea, const float* parts, int64_t part_stride,
+                                                             const float* iwss, const float* iwss_head,
+                                                             const float* iwss_tail, const float* iwss_small,
+                                                             float* out, int64_t out_stride, unsigned* peak_bits) {
+    __shared__ float wave_max[4];
+    const int b = blockIdx.y;
+    float m = 0.f;
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
+         n += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, finalize_sample_parts(ea.L, parts, part_stride, iwss, iwss_head, iwss_tail, iwss_small, out,
+                                           out_stride, b, n));
     if (!peak_bits) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -540,6 +593,12 @@ struct glv_plan {
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
     int recompute = 0;     // iterate without the spectrum state in HBM (MODE_ITER_RC)
     int alias_utts = 0;    // measurement aid: all utterances share one utterance's memory
+    int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
+                            // with runs, 0 = never, 1 = always
+    bool cur_single = false;    // the run table in place is one run per frame
+    float* d_parts = nullptr;   // 2 generations x R partial-sum buffers (one-frame-per-wave modes)
+    size_t parts_cap = 0;       // floats
+    int64_t parts_utt_stride = 0, parts_stride = 0;  // layout of the call in progress
     // device tables
     cf* d_tables = nullptr;
     float* d_w2 = nullptr;
@@ -581,11 +640,12 @@ struct glv_plan {
     // graph cache for the iteration loop
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey {
-        int n_runs, n_iter, with_sc, frames_stride, batch;
+        int n_runs, n_iter, with_sc, frames_stride, batch, single;
         float cmom;
         bool operator==(const GraphKey& o) const {
             return n_runs == o.n_runs && n_iter == o.n_iter && with_sc == o.with_sc &&
-                   frames_stride == o.frames_stride && batch == o.batch && cmom == o.cmom;
+                   frames_stride == o.frames_stride && batch == o.batch && single == o.single &&
+                   cmom == o.cmom;
         }
     } graph_key{};
     // time-shard state (glv_shard_*): frames [t0, t1) of a T-frame utterance live here
@@ -631,6 +691,13 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER1) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ISTFT1) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT1, false>), g, b, lds, st, a);
     } else {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_STFT, false>), g, b, lds, st, a);
     }
@@ -716,7 +783,7 @@ void plan_free(glv_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
     for (void* q : dev)
@@ -767,7 +834,8 @@ void set_io(const glv_plan* p, IterArgs& a, int in, int out) {
 
 // (Re)builds the run table for these lengths and uploads it.  Cached: a call with
 // the lengths of the previous call costs nothing.
-int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st) {
+int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st,
+                 bool single = false) {
     if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
     if (batch < 1 || batch > p->max_batch)
         return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
@@ -778,13 +846,16 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
             return fail(GLV_ERR_INVALID, "n_frames[%d] = %d outside [2, %d]", b, n_frames_host[b],
                         frames_stride);
     const bool same = (int)p->cur_nframes.size() == batch && p->cur_frames_stride == frames_stride &&
-                      p->cur_fpr == p->frames_per_run &&
+                      p->cur_fpr == p->frames_per_run && p->cur_single == single &&
                       memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
     if (same) return GLV_OK;
     // the pinned staging buffers may still feed an earlier call's copies
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<RunDesc> runs;
-    if (p->frames_per_run > 0) {
+    if (single) {
+        for (int b = 0; b < batch; ++b)
+            for (int t = 0; t < n_frames_host[b]; ++t) runs.push_back(RunDesc{b, t, t + 1, n_frames_host[b]});
+    } else if (p->frames_per_run > 0) {
         runs = build_runs(n_frames_host, batch, p->frames_per_run, p->R);
     } else {
         // One wave per run.  Pick the run length so that the runs fill the device's wave
@@ -829,6 +900,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     p->cur_nframes.assign(n_frames_host, n_frames_host + batch);
     p->cur_frames_stride = frames_stride;
     p->cur_fpr = p->frames_per_run;
+    p->cur_single = single;
     p->n_runs = (int)runs.size();
     return GLV_OK;
 }
@@ -975,6 +1047,9 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     if (!strcmp(name, "frames_per_run")) {
         if (value < 0) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 0 (0 = automatic)");
         p->frames_per_run = value;
+    } else if (!strcmp(name, "single_frame")) {
+        if (value < -1 || value > 1) return fail(GLV_ERR_INVALID, "single_frame must be -1 (automatic), 0 or 1");
+        p->single_frame = value;
     } else if (!strcmp(name, "use_graph")) {
         p->use_graph = value != 0;
     } else if (!strcmp(name, "timing")) {
@@ -1087,15 +1162,27 @@ namespace {
 
 // enqueues the n_iter iteration kernels (and nothing else) on st; *last receives the index
 // of the overlap-add generation the final iteration wrote
+// one-frame-per-wave modes: generation g of the R partial-sum buffers
+void set_parts_io(const glv_plan* p, IterArgs& a, int in, int out) {
+    a.y_utt_stride = p->parts_utt_stride;
+    a.part_stride = p->parts_stride;
+    a.part_in = p->d_parts + (size_t)in * p->R * p->parts_stride;
+    a.part_out = p->d_parts + (size_t)out * p->R * p->parts_stride;
+}
+
 int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool with_sc, hipStream_t st,
-                 int* last) {
+                 int* last, bool single = false) {
     IterArgs a = iter_args(p, frames_stride);
     a.cmom = cmom;
     int cur = 0;  // the iSTFT of the initial angles wrote generation 0
     for (int k = 0; k < n_iter; ++k) {
         a.has_prev = k > 0;
         a.sc_partial = with_sc ? p->d_sc_partial + (size_t)k * p->n_runs * 2 : nullptr;
-        if (p->recompute && !p->traffic_only) {
+        if (single) {
+            set_parts_io(p, a, cur, cur ^ 1);
+            HIP_TRY(p->launch_engine(MODE_ITER1, with_sc, a, engine_grid(p), st));
+            cur ^= 1;
+        } else if (p->recompute && !p->traffic_only) {
             // three generations rotate: read `cur` (and the one before it), write the next
             const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
             set_io(p, a, cur, out);
@@ -1131,8 +1218,40 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
+    if (batch < 1 || batch > p->max_batch)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    // A batch with about as many frames as the device has wave slots, or fewer, cannot fill it
+    // with runs of several frames: every frame then gets a wave of its own (partial-sum buffers
+    // instead of a running sum; measured faster up to 1.1x the slots, slower from 1.7x).  Not for
+    // layouts so ragged that the padded buffers would dwarf the payload.
+    int64_t total_frames = 0;
+    for (int b = 0; b < batch; ++b) total_frames += std::max(0, n_frames_host[b]);
+    const int64_t padded_blocks = (int64_t)batch * (frames_stride + p->R);
+    const bool plain = !p->recompute && !p->traffic_only && !p->alias_utts;
+    const bool single = plain && (p->single_frame == 1 ||
+                                  (p->single_frame < 0 && p->frames_per_run == 0 &&
+                                   4 * total_frames <= 5 * (int64_t)p->wave_slots &&
+                                   padded_blocks <= 4 * (int64_t)p->wave_slots));
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single);
     if (rc != GLV_OK) return rc;
+    if (single) {
+        p->parts_utt_stride = (int64_t)(frames_stride + p->R) * p->hop;
+        p->parts_stride = (int64_t)batch * p->parts_utt_stride;
+        const size_t need = (size_t)2 * p->R * p->parts_stride;
+        if (need > p->parts_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (p->d_parts) (void)hipFree(p->d_parts);
+            p->d_parts = nullptr;
+            p->parts_cap = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_parts), need * sizeof(float)));
+            p->parts_cap = need;
+            if (p->graph_exec) {
+                (void)hipGraphExecDestroy(p->graph_exec);
+                p->graph_exec = nullptr;
+            }
+        }
+    }
     int max_t = 0;
     for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
     if (y_stride < (int64_t)p->hop * (max_t - 1))
@@ -1153,7 +1272,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
             }
         }
     }
-    const ElemArgs ea = elem_args(p, batch, frames_stride);
+    ElemArgs ea = elem_args(p, batch, frames_stride);
     const float inv_n = 1.0f / (float)p->n_fft;
     if (src.S_dev) {
         p->launch_init(ea, src.S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec,
@@ -1166,14 +1285,20 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
 
     // inverse = istft(angles) of the initial phase
     IterArgs a = iter_args(p, frames_stride);
-    set_io(p, a, 1, 0);
-    HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
+    if (single) {
+        set_parts_io(p, a, 1, 0);
+        HIP_TRY(p->launch_engine(MODE_ISTFT1, false, a, engine_grid(p), st));
+    } else {
+        set_io(p, a, 1, 0);
+        HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
+    }
 
     const float cmom = momentum / (1.0f + momentum);
     if (p->timing) HIP_TRY(hipEventRecord(p->ev0, st));
     if (n_iter > 0) {
         if (p->use_graph) {
-            const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch, cmom};
+            const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch,
+                                         single ? 1 : 0, cmom};
             if (!p->graph_exec || !(key == p->graph_key)) {
                 if (p->graph_exec) {
                     (void)hipGraphExecDestroy(p->graph_exec);
@@ -1185,7 +1310,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
                 hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
                 int lrc = GLV_OK;
                 if (e == hipSuccess) {
-                    lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap, nullptr);
+                    lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap, nullptr, single);
                     e = hipStreamEndCapture(cap, &graph);
                 }
                 if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
@@ -1200,7 +1325,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
             }
             HIP_TRY(hipGraphLaunch(p->graph_exec, st));
         } else {
-            rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st, nullptr);
+            rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st, nullptr, single);
             if (rc != GLV_OK) return rc;
         }
     }
@@ -1210,11 +1335,19 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     }
     const int last = (p->recompute && !p->traffic_only) ? n_iter % 3 : (n_iter & 1);
     // with the peak gathered on the way every block ends in one atomic on its row's maximum:
-    // few, longer blocks then
-    const unsigned fin_blocks = peak_bits ? std::min<unsigned>(grid_for(y_stride, 256), 32) : grid_for(y_stride, 256);
-    hipLaunchKernelGGL(finalize_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
-                       p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
-                       p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0, peak_bits);
+    // about 2048 blocks in all then
+    const unsigned fin_blocks =
+        peak_bits ? std::min<unsigned>(grid_for(y_stride, 256), std::max(32, 2048 / batch)) : grid_for(y_stride, 256);
+    if (single) {
+        ea.L.y_utt_stride = p->parts_utt_stride;
+        hipLaunchKernelGGL(finalize_parts_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
+                           p->d_parts + (size_t)(n_iter & 1) * p->R * p->parts_stride, p->parts_stride, p->d_iwss,
+                           p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, peak_bits);
+    } else {
+        hipLaunchKernelGGL(finalize_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
+                           p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,
+                           p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, (int64_t)0, peak_bits);
+    }
     HIP_TRY(hipGetLastError());
     if (with_sc) {
         hipLaunchKernelGGL(sc_reduce_kernel, dim3((batch * n_iter + 127) / 128), dim3(128), 0, st,
