@@ -1,13 +1,6 @@
-// libglvoc: HIP kernels (gfx950) and the C ABI declared in include/glvoc.h.
-//
-// Kernel inventory
-//   gl_engine_kernel   one wavefront per run of frames: STFT frame -> phase update ->
-//                      inverse FFT -> register overlap-add (engine.h).  Modes: full
-//                      iteration, iSTFT only, STFT only.  HBM-bound by design:
-//                      per frame it reads tprev (8P B) + S (4P B) + H new samples and
-//                      writes tprev (8P B) + H samples.
-//   mel_invert_kernel  dB -> power fused into an f32 MFMA GEMM with the inverse basis.
-//   init/convert/finalize/peak/sc kernels: element-wise stages (elementwise.h).
+// libglvoc: the plan (tables, workspace, run bookkeeping, graph cache) and the C ABI declared in
+// include/glvoc.h.  The kernels are in kernels.h, the per-wavefront engine in engine.h and
+// wave_fft.h.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -47,537 +40,8 @@ static int fail(int code, const char* fmt, ...) {
 extern "C" const char* glv_last_error(void) { return g_err; }
 extern "C" int glv_version(void) { return 100; }
 
-// ---------------------------------------------------------------------------
-// device code
-// ---------------------------------------------------------------------------
-namespace {
+#include "kernels.h"
 
-#ifndef GLV_WAVES_PER_BLOCK
-#define GLV_WAVES_PER_BLOCK 4
-#endif
-constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
-
-__device__ __forceinline__ void wave_sync() {
-    // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
-    // One wave's DS operations execute in issue order, so no counter wait is needed;
-    // the fences only pin the compiler.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// second launch bound = waves per SIMD the register allocator must leave room for
-#ifndef GLV_MIN_WAVES_A1
-#define GLV_MIN_WAVES_A1 2
-#endif
-#ifndef GLV_MIN_WAVES_A2
-#define GLV_MIN_WAVES_A2 2
-#endif
-template <int A, int HB, int MODE, bool SC>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
-gl_engine_kernel(IterArgs a) {
-    using G = Geo<A>;
-    using Eng = Engine<A, HB>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf* tables = reinterpret_cast<cf*>(smem);
-    for (int i = threadIdx.x; i < G::TABLES; i += blockDim.x) tables[i] = a.tables[i];
-    __syncthreads();
-
-    // wave-uniform values are forced into scalar registers: the compiler cannot see that
-    // threadIdx.x >> 6 (and everything loaded through it) is the same in all 64 lanes
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ri = blockIdx.x * kWavesPerBlock + wave;
-    if (ri >= a.n_runs) return;
-    cf* xb = tables + G::TABLES + wave * G::XBUF;
-
-    RunDesc rd = a.runs[ri];
-    rd.utt = __builtin_amdgcn_readfirstlane(rd.utt);
-    rd.t_begin = __builtin_amdgcn_readfirstlane(rd.t_begin);
-    rd.t_end = __builtin_amdgcn_readfirstlane(rd.t_end);
-    rd.n_frames = __builtin_amdgcn_readfirstlane(rd.n_frames);
-    Eng e;
-    e.init(a, tables, lane, rd);
-    constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
-    constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1;
-    if (kSingle) {
-        // one frame per wave: the run is the frame
-        const int t = e.run.t_begin;
-        if (MODE == MODE_ITER1) {
-            e.template ph0_single<true>(a, t, xb);
-            wave_sync();
-            e.ph1_read(xb);
-            wave_sync();
-            e.ph1_write(xb);
-            wave_sync();
-            e.ph2_read(xb);
-            wave_sync();
-            e.ph2_write(xb);
-            wave_sync();
-            e.template ph3_update<SC, 0, false>(a, t, xb);
-        } else {
-            e.ph3_load(a, t);
-        }
-        wave_sync();
-        e.ph3_write(xb);
-        wave_sync();
-        e.ph4(xb, xb);
-        wave_sync();
-        e.ph5_read(xb);
-        wave_sync();
-        e.ph5_write(xb);
-        wave_sync();
-        e.ph6_single(a, t, xb);
-    }
-    if (!kSingle && MODE != MODE_ISTFT) {
-        e.preload(a);
-        e.prefetch_block(a, e.run.t_begin);
-    }
-    if (MODE == MODE_ITER_RC) {
-        e.preload_prev(a);
-        e.prefetch_block_prev(a, e.run.t_begin);
-    }
-    if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
-    if (kRc) e.prefetch_s(a, e.run.t_begin);
-    for (int t = e.run.t_begin; !kSingle && t < e.run.t_end; ++t) {
-        if (MODE == MODE_TRAFFIC) {
-            e.traffic_frame(a, t);
-            continue;
-        }
-        if (MODE == MODE_ITER_RC) {
-            // forward transform of the same frame of the previous signal -> tprev
-            e.ph0_prev(a, t, xb);
-            wave_sync();
-            e.ph1_read(xb);
-            wave_sync();
-            e.ph1_write(xb);
-            wave_sync();
-            e.ph2_read(xb);
-            wave_sync();
-            e.ph2_write(xb);
-            wave_sync();
-            e.ph3_prev(xb);
-            wave_sync();
-        }
-        if (MODE != MODE_ISTFT) {
-            e.ph0(a, t, xb);
-            wave_sync();
-            e.ph1_read(xb);
-            wave_sync();
-            e.ph1_write(xb);
-            wave_sync();
-            e.ph2_read(xb);
-            wave_sync();
-            e.ph2_write(xb);
-            wave_sync();
-            if (MODE == MODE_STFT) {
-                e.ph3_stft(a, t, xb);
-                wave_sync();
-                continue;
-            }
-            e.template ph3_update<SC, (MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0))>(a, t, xb);
-        } else {
-            e.ph3_load(a, t);
-        }
-        wave_sync();
-        e.ph3_write(xb);
-        wave_sync();
-        e.ph4(xb, xb);
-        wave_sync();
-        e.ph5_read(xb);
-        wave_sync();
-        e.ph5_write(xb);
-        wave_sync();
-        e.ph6(a, t, xb);
-        wave_sync();
-    }
-    if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
-    if (SC) {
-        float num = e.sc_num, den = e.sc_den;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            num += __shfl_xor(num, off);
-            den += __shfl_xor(den, off);
-        }
-        if (lane == 0 && a.sc_partial) {
-            a.sc_partial[2 * ri] = num;
-            a.sc_partial[2 * ri + 1] = den;
-        }
-    }
-}
-
-struct ElemArgs {
-    LayoutArgs L;
-    int batch;
-};
-
-template <int A>
-__global__ void init_native_kernel(ElemArgs ea, const float* S_nat, const cf* phase_nat, uint64_t seed,
-                                   float inv_n, float* S_native, cf* spec) {
-    const int P = ea.L.P;
-    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % P);
-        const int64_t fr = i / P;
-        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-        if (t < (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b]))
-            init_native_element<A>(ea.L, S_nat, phase_nat, seed, inv_n, S_native, spec, b, t, q);
-    }
-}
-
-template <int A, bool TO_NATIVE>
-__global__ void spec_convert_kernel(ElemArgs ea, const cf* src, float inv_n, cf* dst) {
-    const int P = ea.L.P;
-    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % P);
-        const int64_t fr = i / P;
-        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-        if (t >= (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b])) continue;
-        if (TO_NATIVE)
-            spec_to_native_element<A>(ea.L, src, inv_n, dst, b, t, q);
-        else
-            spec_to_natural_element<A>(ea.L, src, dst, b, t, q);
-    }
-}
-
-// caller signal (B, y_stride) -> padded overlap-add coordinates, offset n_fft/2
-__global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride, float* ypad) {
-    const int b = blockIdx.y;
-    const int64_t len = (int64_t)ea.L.hop * (ea.L.n_frames[b] - 1);
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
-         n += (int64_t)gridDim.x * blockDim.x)
-        ypad[(int64_t)b * ea.L.y_utt_stride + ea.L.n_fft / 2 + n] = y[(int64_t)b * y_stride + n];
-}
-
-__global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
-                                                       const unsigned char* tail_flag, int blocks_stride,
-                                                       const float* w2, const float* iwss,
-                                                       const float* iwss_head, const float* iwss_tail,
-                                                       const float* iwss_small, float* out, int64_t out_stride,
-                                                       int64_t n_begin, unsigned* peak_bits) {
-    // samples [n_begin, n_begin + out_stride) of every row; pointers of a time shard are
-    // pre-shifted so that global sample / block indices address them.  With peak_bits the
-    // row maximum of |y| is gathered on the way (one atomic per block, see peak_reduce_kernel).
-    __shared__ float wave_max[4];
-    const int b = blockIdx.y;
-    float m = 0.f;
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
-         n += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, finalize_sample(ea.L, y_main, y_tail, tail_flag, blocks_stride, w2, iwss, iwss_head,
-                                     iwss_tail, iwss_small, out, out_stride, b, n_begin + n));
-    if (!peak_bits) return;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        atomicMax(&peak_bits[b], __float_as_uint(m));
-    }
-}
-
-// finalize_kernel for the one-frame-per-wave modes: the sample is the sum of R partial buffers
-__global__ __launch_bounds__(256) void finalize_parts_kernel(ElemArgs ea, const float* parts, int64_t part_stride,
-                                                             const float* iwss, const float* iwss_head,
-                                                             const float* iwss_tail, const float* iwss_small,
-                                                             float* out, int64_t out_stride, unsigned* peak_bits) {
-    __shared__ float wave_max[4];
-    const int b = blockIdx.y;
-    float m = 0.f;
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < out_stride;
-         n += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, finalize_sample_parts(ea.L, parts, part_stride, iwss, iwss_head, iwss_tail, iwss_small, out,
-                                           out_stride, b, n));
-    if (!peak_bits) return;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        atomicMax(&peak_bits[b], __float_as_uint(m));
-    }
-}
-
-__global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_t y_stride,
-                                                          const int* n_samples, unsigned* peak_bits) {
-    __shared__ float wave_max[4];
-    const int b = blockIdx.y;
-    const int64_t len = n_samples[b];
-    const float* row = y + (int64_t)b * y_stride;
-    float m = 0.f;
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
-         n += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(row[n]));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
-    __syncthreads();
-    // one atomic per block; non-negative floats order like their bit patterns
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        atomicMax(&peak_bits[b], __float_as_uint(m));
-    }
-}
-
-__global__ void peak_scale_kernel(float* y, int64_t y_stride, const int* n_samples,
-                                  const unsigned* peak_bits, float eps) {
-    const int b = blockIdx.y;
-    const int64_t len = n_samples[b];
-    const float denom = __uint_as_float(peak_bits[b]) + eps;
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
-         n += (int64_t)gridDim.x * blockDim.x) {
-        float* p = y + (int64_t)b * y_stride + n;
-        *p = *p / denom;
-    }
-}
-
-// sc[b][k] = sqrt(sum_runs num / sum_runs den); partials are [k][run][2]
-__global__ void sc_reduce_kernel(const float* partial, int n_runs, const int* run_off,
-                                 const int* run_cnt, int batch, int n_iter, float* sc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch * n_iter) return;
-    const int b = i / n_iter, k = i % n_iter;
-    float num = 0.f, den = 0.f;
-    const float* p = partial + ((int64_t)k * n_runs + run_off[b]) * 2;
-    for (int r = 0; r < run_cnt[b]; ++r) {
-        num += p[2 * r];
-        den += p[2 * r + 1];
-    }
-    sc[(int64_t)b * n_iter + k] = sqrtf(num / den);
-}
-
-// C[row][col] = epilogue( sum_k load(X[row][k]) * W[col][k] ): an "NT" GEMM on the f32 MFMA
-// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain).  Block = 4 waves, tile 64 rows x 64 cols,
-// each wave one 32x32 accumulator; operands are staged through LDS in k-chunks of 32.
-//   LOAD_DB    X holds normalised dB; it is converted to power while being staged:
-//              10^(0.1*(x*std + mean)) with numpy's rounding sequence (mel inversion)
-//   EPI_STORE  C = acc                     EPI_CLAMP  C = max(acc, 0)
-//   EPI_SUB    C = acc - D                 EPI_STEP   C = max(D - step*acc, 0)
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kGemmKC = 32;
-enum { EPI_STORE = 0, EPI_CLAMP = 1, EPI_SUB = 2, EPI_STEP = 3 };
-
-template <bool LOAD_DB, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ X,
-                                                      const float* __restrict__ W, int64_t rows, int K,
-                                                      int cols, float mean, float std_, float step,
-                                                      const float* D, float* C) {
-    __shared__ float sa[64][kGemmKC + 1];
-    __shared__ float sb[64][kGemmKC + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t row0 = (int64_t)blockIdx.y * 64;
-    const int col0 = blockIdx.x * 64;
-    const int wr = wave >> 1, wc = wave & 1;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += kGemmKC) {
-        for (int i = threadIdx.x; i < 64 * kGemmKC; i += 256) {
-            const int r = i / kGemmKC, k = i % kGemmKC;
-            float pa = 0.f, pb = 0.f;
-            if (k0 + k < K) {
-                if (row0 + r < rows) {
-                    pa = X[(row0 + r) * K + k0 + k];
-                    if (LOAD_DB) {
-                        // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
-                        const float x = __fadd_rn(__fmul_rn(pa, std_), mean);
-                        pa = powf(10.0f, __fmul_rn(0.1f, x));
-                    }
-                }
-                if (col0 + r < cols) pb = W[(int64_t)(col0 + r) * K + k0 + k];
-            }
-            sa[r][k] = pa;
-            sb[r][k] = pb;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kGemmKC; k += 2) {
-            const float av = sa[wr * 32 + (lane & 31)][k + (lane >> 5)];
-            const float bv = sb[wc * 32 + (lane & 31)][k + (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = col0 + wc * 32 + (lane & 31);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int64_t row = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < rows && col < cols) {
-            const int64_t at = row * cols + col;
-            float v = acc[reg];
-            if (EPI == EPI_CLAMP) v = fmaxf(v, 0.f);
-            if (EPI == EPI_SUB) v = v - D[at];
-            if (EPI == EPI_STEP) v = fmaxf(D[at] - step * v, 0.f);
-            C[at] = v;
-        }
-    }
-}
-
-// Mel inversion fused with the set-up of the iteration state: for a block of 32 frames the
-// normalised-dB mel is turned into power once (LDS) and multiplied with the inverse basis on
-// the f32 MFMA, 32 bins per wave and step (the same fma chain as gemm_nt_kernel<true,
-// EPI_STORE>, so S is bit-identical).  The magnitudes of 512 bins x 32 frames are collected in
-// LDS, then every wave writes whole native rows: 16-byte stores of S and of the initial
-// angles phase * S / n_fft - what gemm_nt_kernel + init_native_kernel do through a (rows, F)
-// array in HBM.
-//   Wt  inverse basis transposed and zero-padded: [Mp][Fp], Mp a multiple of 16, Fp >= P + 32
-constexpr int kMelWaves = 8;         // waves per block of mel_native_kernel
-constexpr int kMelTileStride = 520;  // floats per frame of the LDS magnitude tile (512 + 8: the
-                                     // accumulator rows 4 apart fall on different banks)
-template <int A>
-__global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea, const float* __restrict__ mel_db,
-                                                         const float* __restrict__ Wt, int M, int Mp, int Fp,
-                                                         float mean, float std_, const cf* phase_nat,
-                                                         uint64_t seed, float inv_n, float* S_native,
-                                                         cf* spec) {
-    extern __shared__ float mel_smem[];
-    const int lds = Mp + 1;
-    float* sa = mel_smem;                          // [32][Mp + 1] mel power of this block's frames
-    float* tile = sa + 32 * lds;               // [32][kMelTileStride] magnitudes of one half
-    float* nyq = tile + 32 * kMelTileStride;   // [32] magnitudes of the Nyquist bin
-    const int P = ea.L.P, F = ea.L.F;
-    const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
-    const int64_t row0 = (int64_t)blockIdx.x * 32;
-    for (int i = threadIdx.x; i < 32 * Mp; i += 64 * kMelWaves) {
-        const int r = i / Mp, k = i % Mp;
-        float pa = 0.f;
-        if (k < M && row0 + r < rows) {
-            // same rounding sequence as numpy: (mel*std)+mean, 0.1*x, 10**e
-            const float x = __fadd_rn(__fmul_rn(mel_db[(row0 + r) * M + k], std_), mean);
-            pa = powf(10.0f, __fmul_rn(0.1f, x));
-        }
-        sa[r * lds + k] = pa;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* arow = sa + (lane & 31) * lds + (lane >> 5);
-    auto product = [&](int col0) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const float* bcol = Wt + (int64_t)(lane >> 5) * Fp + col0 + (lane & 31);
-        // operands of 8 steps are fetched together so their latencies overlap (Mp is a multiple
-        // of 16; the padding rows are zero and add nothing)
-        for (int k0 = 0; k0 < Mp; k0 += 16) {
-            float av[8], bv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bv[i] = bcol[(int64_t)(k0 + 2 * i) * Fp];
-                av[i] = arow[k0 + 2 * i];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
-        }
-        return acc;
-    };
-    // frame (0..31) of accumulator register `reg` in this lane
-    auto acc_frame = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); };
-    if (wave == kMelWaves - 1) {
-        const f32x16 acc = product(P);
-        if ((lane & 31) == 0) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) nyq[acc_frame(reg)] = acc[reg];
-        }
-    }
-    auto phase_at = [&](int64_t fr, int k) -> cf {
-        if (phase_nat) return phase_nat[fr * F + k];
-        return counter_phasor(seed, (uint64_t)((fr + ea.L.frame_origin) * F + k));
-    };
-    const int low = (lane >> 3) + 8 * (lane & 7);  // this lane's bin modulo 64 on the frequency side
-    for (int h = 0; h < A; ++h) {
-        for (int c = wave; c < 16; c += kMelWaves) {
-            const f32x16 acc = product(512 * h + 32 * c);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) tile[acc_frame(reg) * kMelTileStride + 32 * c + (lane & 31)] = acc[reg];
-        }
-        __syncthreads();
-        for (int f = wave * (32 / kMelWaves); f < (wave + 1) * (32 / kMelWaves); ++f) {
-            const int64_t fr = row0 + f;
-            if (fr >= rows) break;
-            const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-            if (t >= (ea.L.frames_local > 0 ? ea.L.frames_local : ea.L.n_frames[b])) continue;
-            float* snat = S_native + fr * (P + 4);
-            f4* sp = reinterpret_cast<f4*>(spec + fr * P);
-            const float* trow = tile + f * kMelTileStride + low;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float s4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s4[j] = trow[64 * (4 * g + j)];
-                reinterpret_cast<f4*>(snat)[(2 * h + g) * 64 + lane] = f4{s4[0], s4[1], s4[2], s4[3]};
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    const int ka = 512 * h + low + 64 * (4 * g + 2 * pp);
-                    const cf pa = phase_at(fr, ka), pb = phase_at(fr, ka + 64);
-                    const float sa2 = s4[2 * pp], sb2 = s4[2 * pp + 1];
-                    cf aa = cf{pa.x * sa2 * inv_n, pa.y * sa2 * inv_n};
-                    const cf ab = cf{pb.x * sb2 * inv_n, pb.y * sb2 * inv_n};
-                    if (ka == 0) {
-                        // DC and Nyquist are real and share native bin 0 (c2r ignores their Im)
-                        const cf pn = phase_at(fr, P);
-                        aa.y = pn.x * nyq[f] * inv_n;
-                    }
-                    sp[(4 * h + 2 * g + pp) * 64 + lane] = f4{aa.x, aa.y, ab.x, ab.y};
-                }
-            }
-            if (h == 0 && lane == 0) reinterpret_cast<f4*>(snat + P)[0] = f4{nyq[f], 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-    }
-}
-
-// native spectrum -> natural-order power |D|^2, (rows, F) float32 (librosa's _spectrogram, power=2)
-template <int A>
-__global__ void spec_power_kernel(ElemArgs ea, const cf* spec, float* power) {
-    const int P = ea.L.P, F = ea.L.F;
-    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * P;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % P);
-        const int64_t fr = i / P;
-        const int t = (int)(fr % ea.L.frames_stride), b = (int)(fr / ea.L.frames_stride);
-        const bool live = t < ea.L.n_frames[b];
-        const int reg = q >> 6, lane = q & 63;
-        const int k = Geo<A>::bin(reg, lane);
-        const cf d = live ? spec[fr * P + native_spec_index(reg, lane)] : cf{0.f, 0.f};
-        if (q == 0) {
-            power[fr * F] = d.x * d.x;       // DC and Nyquist share native bin 0
-            power[fr * F + P] = d.y * d.y;
-        } else {
-            power[fr * F + k] = d.x * d.x + d.y * d.y;
-        }
-    }
-}
-
-// librosa.power_to_db: 10*log10(max(amin, x)) - 10*log10(max(amin, ref)), floored at
-// (its own maximum - top_db) when top_db >= 0.  ref is ref_dev[b] (per utterance) or ref_value.
-__global__ void power_to_db_kernel(const float* x, int64_t stride, const int* n_valid, const float* ref_dev,
-                                   float ref_value, float amin, float top_db, const float* max_dev,
-                                   float* out) {
-    const int b = blockIdx.y;
-    const int64_t len = n_valid[b];
-    const float ref = ref_dev ? ref_dev[b] : ref_value;
-    const float ref_db = 10.0f * log10f(fmaxf(amin, ref));
-    // the largest output is that of the largest input
-    const float floor_db = 10.0f * log10f(fmaxf(amin, max_dev[b])) - ref_db - top_db;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 10.0f * log10f(fmaxf(amin, x[b * stride + i])) - ref_db;
-        if (top_db >= 0.f) v = fmaxf(v, floor_db);
-        out[b * stride + i] = v;
-    }
-}
-
-// x -> x^(1/power), in place (librosa.feature.inverse.mel_to_stft's last step)
-__global__ void root_kernel(float* x, int64_t n, float inv_power) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        x[i] = (inv_power == 0.5f) ? sqrtf(x[i]) : powf(x[i], inv_power);
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------
 // plan
