@@ -98,6 +98,9 @@ def main():
                     help="measurement aid: all utterances share one utterance's memory (cache-resident loop)")
     ap.add_argument("--traffic-only", action="store_true",
                     help="measurement aid: iteration kernels move their data but compute nothing")
+    ap.add_argument("--linear", type=int, default=-1,
+                    help="1/0: momentum term formed in the time domain / in the frequency domain "
+                         "(default -1: library default)")
     ap.add_argument("--single-frame", type=int, default=-1,
                     help="1/0: force / forbid the one-frame-per-wave iteration (default -1: library choice)")
     ap.add_argument("--unfused", action="store_true",
@@ -143,6 +146,8 @@ def main():
         plan.set_option("traffic_only", 1)
     if args.alias_utts:
         plan.set_option("alias_utts", 1)
+    if args.linear >= 0:
+        plan.set_option("linear", args.linear)
     if args.single_frame >= 0:
         plan.set_option("single_frame", args.single_frame)
     if args.recompute >= 0:

@@ -210,6 +210,10 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 /*
  * Tuning and measurement hooks (no counterpart in the reference).
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
+ *                        "linear" (1/0, default 1: form the momentum term in the time domain -
+ *                        rebuilt_k - c*rebuilt_{k-1} = STFT(y_k - c*y_{k-1}) - so that no spectrum
+ *                        state is kept in memory; 0 = subtract the stored previous spectrum as
+ *                        librosa writes it; equal up to rounding),
  *                        "single_frame" (-1 automatic / 0 / 1: give every frame a wavefront of its
  *                        own - R partial-sum buffers instead of a running sum - which is what a
  *                        batch with fewer frames than the device has wave slots needs; automatic

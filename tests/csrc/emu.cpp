@@ -59,7 +59,14 @@ void emu_launch(const IterArgs& a) {
         }
         constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
         constexpr int kRcArg = MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0);
-        if (MODE != MODE_ISTFT)
+        if (MODE == MODE_ITER_LIN)
+            for (int l = 0; l < 64; ++l) {
+                e[l].template preload_lin<SC>(a);
+                e[l].prefetch_block(a, run.t_begin);
+                e[l].prefetch_block_prev(a, run.t_begin);
+                e[l].prefetch_s(a, run.t_begin);
+            }
+        if (MODE != MODE_ISTFT && MODE != MODE_ITER_LIN)
             for (int l = 0; l < 64; ++l) {
                 e[l].preload(a);
                 e[l].prefetch_block(a, run.t_begin);
@@ -82,7 +89,26 @@ void emu_launch(const IterArgs& a) {
                 for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph3_prev(b0.data());
             }
-            if (MODE != MODE_ISTFT) {
+            if (MODE == MODE_ITER_LIN) {
+                for (int l = 0; l < 64; ++l) e[l].template lin_advance<SC>(a, t);
+                if (SC) {
+                    for (int l = 0; l < 64; ++l) e[l].lin_window_signal(b0.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph3_metric(b0.data());
+                }
+                for (int l = 0; l < 64; ++l) {
+                    e[l].lin_window_combined(b0.data());
+                    e[l].template lin_shift<SC>();
+                }
+                for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].template ph3_update<false, 2>(a, t, b0.data());
+            } else if (MODE != MODE_ISTFT) {
                 for (int l = 0; l < 64; ++l) e[l].ph0(a, t, b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
@@ -239,7 +265,7 @@ struct Emu {
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
-                   float* y, int64_t y_stride, float* sc, bool recompute) {
+                   float* y, int64_t y_stride, float* sc, bool recompute, bool linear = false) {
         for (int b = 0; b < batch; ++b)
             for (int t = 0; t < nf[b]; ++t)
                 for (int q = 0; q < P; ++q)
@@ -253,7 +279,17 @@ struct Emu {
         for (int k = 0; k < n_iter; ++k) {
             a.has_prev = k > 0;
             a.sc_partial = sc ? sc_partial.data() : nullptr;
-            if (recompute) {
+            if (linear) {
+                // three generations rotate; the first iteration has no older signal (c = 0,
+                // the pointer only has to be readable)
+                const int out = (cur + 1) % 3, prev = k == 0 ? cur : (cur + 2) % 3;
+                io(cur, out);
+                a.y_prev = ym[prev].data();
+                a.y_prev_tail = yt[prev].data();
+                if (sc) emu_launch<A, HB, MODE_ITER_LIN, true>(a);
+                else emu_launch<A, HB, MODE_ITER_LIN, false>(a);
+                cur = out;
+            } else if (recompute) {
                 const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
                 io(cur, out);
                 a.y_prev = ym[prev].data();
@@ -341,11 +377,12 @@ int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const flo
                    uint64_t seed, const int* n_frames, int batch, int frames_stride, int n_iter,
                    float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc, int recompute) {
     // recompute: 0 = run-based iteration, 1 = its recompute-the-previous-spectrum variant,
-    //            2 = one frame per wave
+    //            2 = one frame per wave, 3 = momentum in the time domain
     return dispatch(n_fft, hop, [&](auto* tag) {
         using E = std::remove_pointer_t<decltype(tag)>;
         E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
         if (recompute == 2) return e.griffinlim_single(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
+        if (recompute == 3) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, true);
         return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, recompute != 0);
     });
 }

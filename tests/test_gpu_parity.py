@@ -576,3 +576,42 @@ def test_one_frame_per_wave_mode(voc, O, n_fft, hop, win, lens):
                            n_fft=n_fft, init_phase=from_btf2(p[b, :t]))
         assert rel_l2(y2[b, :n], ref) < 1e-4
     plan.close()
+
+
+@pytest.mark.parametrize("n_fft,hop,win,lens,fpr", [(1024, 256, 1024, [120, 33, 7], 12), (2048, 256, 2048, [96, 40], 12),
+                                                    (2048, 512, 1200, [64], 7), (1024, 128, 1024, [50, 9], 0),
+                                                    (2048, 1024, 2048, [12, 5], 0), (1024, 512, 800, [40], 3)])
+def test_momentum_in_time_domain_and_in_frequency_domain(voc, O, n_fft, hop, win, lens, fpr):
+    """The run-based iteration in its two forms - momentum term formed before the forward
+    transform (option linear = 1, the default: no spectrum state in memory) or by subtracting
+    the stored previous spectrum (linear = 0) - against the oracle and against each other."""
+    f = n_fft // 2 + 1
+    t_max = max(lens)
+    rng = np.random.default_rng(3 + t_max)
+    s = np.zeros((len(lens), t_max, f), np.float32)
+    p = np.zeros((len(lens), t_max, f, 2), np.float32)
+    for b, t in enumerate(lens):
+        s[b, :t] = rng.standard_normal((t, f)) ** 2
+        s[b, :t, ::7] *= -0.3
+        ang = 2 * np.pi * rng.random((t, f))
+        p[b, :t, :, 0], p[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, win, 80, t_max, len(lens))
+    plan.set_option("single_frame", 0)
+    plan.set_option("frames_per_run", fpr)
+    out = {}
+    for linear in (1, 0):
+        plan.set_option("linear", linear)
+        y, sc = plan.griffinlim(dev(s), lens, phase0=dev(p), n_iter=8, return_sc=True)
+        y_nosc = plan.griffinlim(dev(s), lens, phase0=dev(p), n_iter=8)
+        assert torch.equal(y, y_nosc)          # asking for the curve does not change the waveform
+        out[linear] = (y.cpu().numpy(), sc.cpu().numpy())
+    for b, t in enumerate(lens):
+        n = hop * (t - 1)
+        ref, sc_ref = O.griffinlim(np.ascontiguousarray(s[b, :t].T), n_iter=8, hop_length=hop, win_length=win,
+                                   n_fft=n_fft, init_phase=from_btf2(p[b, :t]), return_sc=True)
+        for linear in (1, 0):
+            y, sc = out[linear]
+            assert rel_l2(y[b, :n], ref) < 1e-4, linear
+            assert np.all(y[b, n:] == 0)
+            assert np.max(np.abs(sc[b] - sc_ref) / sc_ref) < 1e-4, linear
+    plan.close()

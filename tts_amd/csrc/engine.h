@@ -71,6 +71,11 @@ struct RunDesc {
 // MODE_ITER_RC / MODE_ITER_RC_FIRST: the iteration without the spectrum state in HBM - the
 // previous rebuilt spectrum (the momentum term) is recomputed from the previous signal,
 // which costs one more forward FFT per frame and saves reading and writing 8P bytes.
+// MODE_ITER_LIN: the momentum term taken in the time domain.  The STFT is linear, so
+// rebuilt_k - c * rebuilt_{k-1} = STFT(y_k - c * y_{k-1}): one forward transform of the combined
+// signal replaces the spectrum state (read 8P, write 8P bytes per frame) by one more read of
+// H samples.  Same arithmetic up to rounding; the convergence metric, which needs |rebuilt_k|
+// itself, costs a second forward transform only when it is asked for.
 // MODE_ITER1 / MODE_ISTFT1: one frame per wave, for batches too small to fill the device with
 // runs.  There is no running sum: a frame's windowed output goes, as R whole blocks, to
 // partial-sum buffer (t mod R), and a reader adds the R buffers (see load_frame_from_parts).
@@ -82,7 +87,8 @@ enum Mode {
     MODE_ITER_RC = 4,
     MODE_ITER_RC_FIRST = 5,
     MODE_ITER1 = 6,
-    MODE_ISTFT1 = 7
+    MODE_ISTFT1 = 7,
+    MODE_ITER_LIN = 8
 };
 
 struct IterArgs {
@@ -364,6 +370,73 @@ struct Engine {
         F::split_fwd(v, m, tab, lane);
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) tp_n[reg] = v[reg];
+    }
+
+    // ---- MODE_ITER_LIN: the sliding window holds y_k - c * y_{k-1}; with the metric wanted,
+    // `rawp` holds y_k alone beside it ----
+    template <bool SC>
+    GLV_HD void preload_lin(const IterArgs& a) {
+        const float c = a.has_prev ? a.cmom : 0.0f;
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) {
+            load_block(a, a.y_in, a.y_in_tail, run.t_begin + q, raw, q * HB);
+            load_block(a, a.y_prev, a.y_prev_tail, run.t_begin + q, v, q * HB);
+        }
+        combine_rows<SC, 0, (R - 1) * HB>(c);
+    }
+    // rows [row0, row1) of every sub-sequence: raw = y_k - c * y_{k-1} (y_{k-1} sits in v)
+    template <bool SC, int ROW0, int ROW1>
+    GLV_HD void combine_rows(float c) {
+#pragma unroll
+        for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+            for (int r = ROW0; r < ROW1; ++r) {
+                const int k = r + 8 * s2;
+                if (SC) rawp[k] = raw[k];
+                raw[k] = cf{fmaf(-c, v[k].x, raw[k].x), fmaf(-c, v[k].y, raw[k].y)};
+            }
+    }
+    // newest block of both signals into the windows, loads for the next frame issued
+    template <bool SC>
+    GLV_HD void lin_advance(const IterArgs& a, int t) {
+        finish_block(a, blk_n, raw, (R - 1) * HB);
+        finish_block(a, blkp_n, v, (R - 1) * HB);
+        prefetch_block(a, t + 1);
+        prefetch_block_prev(a, t + 1);
+        combine_rows<SC, (R - 1) * HB, R * HB>(a.has_prev ? a.cmom : 0.0f);
+    }
+    // window one of the two arrays and start its forward transform
+    GLV_HD void lin_window(const cf (&src)[E], cf* w) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const cf wn = tab.win[r * 64 + lane];
+            v[r] = cf{src[r].x * wn.x, src[r].y * wn.y};
+        }
+        F::fwd_a(v, tab, w, lane);
+    }
+    GLV_HD void lin_window_signal(cf* w) { lin_window(rawp, w); }
+    GLV_HD void lin_window_combined(cf* w) { lin_window(raw, w); }
+    template <bool SC>
+    GLV_HD void lin_shift() {
+        shift_rows(raw);
+        if (SC) shift_rows(rawp);
+    }
+    // the spectrum of y_k alone exists only for the convergence metric
+    GLV_HD void ph3_metric(const cf* r) {
+        cf m[E];
+        F::mirror_load(m, r, mbase);
+        F::split_fwd(v, m, tab, lane);
+#pragma unroll
+        for (int reg = 0; reg < E; ++reg) {
+            const cf x = v[reg];
+            const bool packed = (reg == 0) && (lane == 0);
+            const float sx = s_n[reg], sy = packed ? s_nyq_n : s_n[reg];
+            const float mag = sqrtf(x.x * x.x + x.y * x.y);
+            const float ex = (packed ? fabsf(x.x) : mag) - fabsf(sx);
+            const float ey = packed ? fabsf(x.y) - fabsf(sy) : 0.f;
+            sc_num += ex * ex + ey * ey;
+            sc_den += sx * sx + (packed ? sy * sy : 0.f);
+        }
     }
 
     // ---- phase 0: newest block, window, first DFT pass ----

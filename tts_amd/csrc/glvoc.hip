@@ -57,6 +57,8 @@ struct glv_plan {
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
     int recompute = 0;     // iterate without the spectrum state in HBM (MODE_ITER_RC)
     int alias_utts = 0;    // measurement aid: all utterances share one utterance's memory
+    int linear = 1;        // momentum term formed in the time domain (MODE_ITER_LIN): no spectrum state
+                           // in memory; 0 = in the frequency domain as librosa writes it (MODE_ITER)
     int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
                             // with runs, 0 = never, 1 = always
     bool cur_single = false;    // the run table in place is one run per frame
@@ -160,6 +162,11 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_LIN) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT1) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT1, false>), g, b, lds, st, a);
     } else {
@@ -511,6 +518,12 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     if (!strcmp(name, "frames_per_run")) {
         if (value < 0) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 0 (0 = automatic)");
         p->frames_per_run = value;
+    } else if (!strcmp(name, "linear")) {
+        p->linear = value != 0;
+        if (p->graph_exec) {
+            (void)hipGraphExecDestroy(p->graph_exec);
+            p->graph_exec = nullptr;
+        }
     } else if (!strcmp(name, "single_frame")) {
         if (value < -1 || value > 1) return fail(GLV_ERR_INVALID, "single_frame must be -1 (automatic), 0 or 1");
         p->single_frame = value;
@@ -626,6 +639,10 @@ namespace {
 
 // enqueues the n_iter iteration kernels (and nothing else) on st; *last receives the index
 // of the overlap-add generation the final iteration wrote
+// the loop rotates three signal generations (instead of two) in the variants that read the
+// previous signal
+bool three_generations(const glv_plan* p) { return !p->traffic_only && (p->recompute || p->linear); }
+
 // one-frame-per-wave modes: generation g of the R partial-sum buffers
 void set_parts_io(const glv_plan* p, IterArgs& a, int in, int out) {
     a.y_utt_stride = p->parts_utt_stride;
@@ -646,6 +663,16 @@ int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool wi
             set_parts_io(p, a, cur, cur ^ 1);
             HIP_TRY(p->launch_engine(MODE_ITER1, with_sc, a, engine_grid(p), st));
             cur ^= 1;
+        } else if (three_generations(p) && !p->recompute) {
+            // momentum in the time domain: read this signal and the one before it, write the
+            // next.  The first iteration has no older signal: its weight is zero and the
+            // pointer only has to be readable.
+            const int out = (cur + 1) % 3, prev = k == 0 ? cur : (cur + 2) % 3;
+            set_io(p, a, cur, out);
+            a.y_prev = p->d_ym[prev];
+            a.y_prev_tail = p->d_yt[prev];
+            HIP_TRY(p->launch_engine(MODE_ITER_LIN, with_sc, a, engine_grid(p), st));
+            cur = out;
         } else if (p->recompute && !p->traffic_only) {
             // three generations rotate: read `cur` (and the one before it), write the next
             const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
@@ -797,7 +824,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         HIP_TRY(hipEventRecord(p->ev1, st));
         p->ev_valid = true;
     }
-    const int last = (p->recompute && !p->traffic_only) ? n_iter % 3 : (n_iter & 1);
+    const int last = three_generations(p) ? n_iter % 3 : (n_iter & 1);
     // with the peak gathered on the way every block ends in one atomic on its row's maximum:
     // about 2048 blocks in all then
     const unsigned fin_blocks =

@@ -63,7 +63,7 @@ gl_engine_kernel(IterArgs a) {
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             const int i = threadIdx.x + k * kThreads;
-            if (i < kVec) tmp[k] = src[i];
+            tmp[k] = src[i < kVec ? i : kVec - 1];
         }
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
@@ -118,13 +118,20 @@ gl_engine_kernel(IterArgs a) {
         wave_sync();
         e.ph6_single(a, t, xb);
     }
-    if (!kSingle && MODE != MODE_ISTFT) {
+    constexpr bool kLin = MODE == MODE_ITER_LIN;
+    if (!kSingle && !kLin && MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
     }
     if (MODE == MODE_ITER_RC) {
         e.preload_prev(a);
         e.prefetch_block_prev(a, e.run.t_begin);
+    }
+    if (MODE == MODE_ITER_LIN) {
+        e.template preload_lin<SC>(a);
+        e.prefetch_block(a, e.run.t_begin);
+        e.prefetch_block_prev(a, e.run.t_begin);
+        e.prefetch_s(a, e.run.t_begin);
     }
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     if (kRc) e.prefetch_s(a, e.run.t_begin);
@@ -148,7 +155,37 @@ gl_engine_kernel(IterArgs a) {
             e.ph3_prev(xb);
             wave_sync();
         }
-        if (MODE != MODE_ISTFT) {
+        if (kLin) {
+            e.template lin_advance<SC>(a, t);
+            if (SC) {
+                // the metric needs the spectrum of the signal itself: a transform of its own
+                e.lin_window_signal(xb);
+                wave_sync();
+                e.ph1_read(xb);
+                wave_sync();
+                e.ph1_write(xb);
+                wave_sync();
+                e.ph2_read(xb);
+                wave_sync();
+                e.ph2_write(xb);
+                wave_sync();
+                e.ph3_metric(xb);
+                wave_sync();
+            }
+            e.lin_window_combined(xb);
+            e.template lin_shift<SC>();
+            wave_sync();
+            e.ph1_read(xb);
+            wave_sync();
+            e.ph1_write(xb);
+            wave_sync();
+            e.ph2_read(xb);
+            wave_sync();
+            e.ph2_write(xb);
+            wave_sync();
+            // v = STFT(y_k - c y_{k-1}): normalise, scale by S; nothing to fetch or store
+            e.template ph3_update<false, 2>(a, t, xb);
+        } else if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
             wave_sync();
             e.ph1_read(xb);
