@@ -161,6 +161,19 @@ GLV_HD void st_stream(cf* p, cf v) { *p = v; }
 GLV_HD void st_stream(f4* p, f4 v) { *p = v; }
 #endif
 
+// 1 / (sqrt(x) + tiny) for x >= 0 without the square root: the hardware reciprocal square root
+// (1 ulp), with the argument kept off zero so that a vanishing bin gives 0 * finite = 0 as
+// 0 / (0 + tiny) does.  (Bins below 1e-19 in magnitude come out scaled down instead of
+// normalised; they carry no signal.)
+GLV_HD float inv_norm(float x) {
+    const float xs = fmaxf(x, 1.17549435e-38f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(xs);
+#else
+    return 1.0f / sqrtf(xs);
+#endif
+}
+
 GLV_HD float rcp_refined(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r = __builtin_amdgcn_rcpf(x);
@@ -517,11 +530,15 @@ struct Engine {
                     sc_den += sx * sx + (packed ? sy * sy : 0.f);
                 }
                 const cf d = cf{x.x - cmom * tp_n[reg].x, x.y - cmom * tp_n[reg].y};
-                const float mag = sqrtf(d.x * d.x + d.y * d.y);
-                const float mx = packed ? fabsf(d.x) : mag;
-                const float my = packed ? fabsf(d.y) : mag;
-                const float ix = rcp_refined(mx + kTiny) * a.inv_n;
-                const float iy = packed ? rcp_refined(my + kTiny) * a.inv_n : ix;
+                // angles / (|angles| + tiny): one reciprocal square root per bin
+                float ix = inv_norm(d.x * d.x + d.y * d.y) * a.inv_n, iy = ix;
+                if (reg == 0) {
+                    // lane 0 holds two real bins here
+                    const float px = rcp_refined(fabsf(d.x) + kTiny) * a.inv_n;
+                    const float py = rcp_refined(fabsf(d.y) + kTiny) * a.inv_n;
+                    ix = packed ? px : ix;
+                    iy = packed ? py : iy;
+                }
                 v[reg] = cf{d.x * ix * sx, d.y * iy * sy};
             }
             if (CH < E) GLV_SCHED_FENCE();
