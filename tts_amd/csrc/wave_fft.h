@@ -31,24 +31,94 @@
 
 namespace glv {
 
+// A complex value.  Under hipcc it is a two-float vector, so that sums and differences are
+// packed-fp32 instructions on register pairs without help from the vectoriser; a host compiler
+// (the emulation in tests/csrc) sees a plain struct.
+#if defined(__HIP__)
+typedef float cf __attribute__((ext_vector_type(2)));
+#else
 struct cf {
     float x, y;
 };
 GLV_HD cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
 GLV_HD cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-// a * b
-GLV_HD cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-// a * conj(b)
-GLV_HD cf cmulc(cf a, cf b) { return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+#endif
+// Complex primitives.  On the device each is written as the packed-fp32 instructions it needs,
+// with operand half selection (op_sel: which half of a source feeds the low / the high result)
+// and per-half negation: a complex product is two instructions, a sum with a rotated or
+// conjugated operand one.  Left to vectorise the scalar forms, the compiler computes sum and
+// difference for both halves and moves one of each away - about twice the instructions.
+#ifndef GLV_PK_ASM
+#define GLV_PK_ASM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && GLV_PK_ASM
+#define GLV_PK2(name, text)                          \
+    __device__ __forceinline__ cf name(cf a, cf b) { \
+        cf r;                                        \
+        asm(text : "=v"(r) : "v"(a), "v"(b));        \
+        return r;                                    \
+    }
+// a + i*b, a - i*b, a + conj(b), a - conj(b)
+GLV_PK2(addi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+GLV_PK2(subi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+GLV_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1] neg_hi:[0,1]")
+GLV_PK2(sub_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1]")
+#undef GLV_PK2
+// a * b:       t = (a.x*b.x,  a.x*b.y);  r = (-a.y*b.y + t.lo, a.y*b.x + t.hi)
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a * conj(b): t = (a.x*b.x, -a.x*b.y);  r = ( a.y*b.y + t.lo, a.y*b.x + t.hi)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// k*a - i*u and a + i*k*u for a real constant k (both halves of kk hold it)
+__device__ __forceinline__ cf scale_subi(cf a, cf kk, cf u) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]"
+        : "=v"(r)
+        : "v"(a), "v"(kk), "v"(u));
+    return r;
+}
+__device__ __forceinline__ cf add_scaled_i(cf a, cf kk, cf u) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(u), "v"(kk), "v"(a));
+    return r;
+}
+#else
+GLV_HD cf addi(cf a, cf b) { return cf{a.x - b.y, a.y + b.x}; }
+GLV_HD cf subi(cf a, cf b) { return cf{a.x + b.y, a.y - b.x}; }
+GLV_HD cf add_conj(cf a, cf b) { return cf{a.x + b.x, a.y - b.y}; }
+GLV_HD cf sub_conj(cf a, cf b) { return cf{a.x - b.x, a.y + b.y}; }
+GLV_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+GLV_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+GLV_HD cf scale_subi(cf a, cf kk, cf u) { return cf{kk.x * a.x + u.y, kk.y * a.y - u.x}; }
+GLV_HD cf add_scaled_i(cf a, cf kk, cf u) { return cf{a.x - kk.x * u.y, a.y + kk.y * u.x}; }
+#endif
+GLV_HD cf scale(cf a, float k) { return cf{a.x * k, a.y * k}; }
 // forward twiddles are stored as e^{-i*theta}; INV selects the conjugate
 template <bool INV>
 GLV_HD cf twmul(cf a, cf w) {
     return INV ? cmulc(a, w) : cmul(a, w);
 }
-// multiply by -i (forward) or +i (inverse)
+// a + w*b and a - w*b for w = -i (forward) or +i (inverse)
 template <bool INV>
-GLV_HD cf rot90(cf a) {
-    return INV ? cf{-a.y, a.x} : cf{a.y, -a.x};
+GLV_HD cf add_rot(cf a, cf b) {
+    return INV ? addi(a, b) : subi(a, b);
+}
+template <bool INV>
+GLV_HD cf sub_rot(cf a, cf b) {
+    return INV ? subi(a, b) : addi(a, b);
 }
 
 // ---------------------------------------------------------------------------
@@ -61,11 +131,11 @@ template <bool INV>
 struct Dft<4, INV> {
     static GLV_HD void run(cf (&v)[4]) {
         const cf s02 = v[0] + v[2], d02 = v[0] - v[2];
-        const cf s13 = v[1] + v[3], d13 = rot90<INV>(v[1] - v[3]);
+        const cf s13 = v[1] + v[3], d13 = v[1] - v[3];
         v[0] = s02 + s13;
-        v[1] = d02 + d13;
+        v[1] = add_rot<INV>(d02, d13);
         v[2] = s02 - s13;
-        v[3] = d02 - d13;
+        v[3] = sub_rot<INV>(d02, d13);
     }
 };
 
@@ -79,22 +149,21 @@ struct Dft<8, INV> {
             b[n] = v[n] + v[n + 4];
             c[n] = v[n] - v[n + 4];
         }
-        // c[n] *= W8^n
-        if (INV) {
-            c[1] = cf{(c[1].x - c[1].y) * h, (c[1].x + c[1].y) * h};
-            c[3] = cf{-(c[3].x + c[3].y) * h, (c[3].x - c[3].y) * h};
-        } else {
-            c[1] = cf{(c[1].x + c[1].y) * h, (c[1].y - c[1].x) * h};
-            c[3] = cf{(c[3].y - c[3].x) * h, -(c[3].x + c[3].y) * h};
-        }
-        c[2] = rot90<INV>(c[2]);
         Dft<4, INV>::run(b);
-        Dft<4, INV>::run(c);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[2 * k] = b[k];
-            v[2 * k + 1] = c[k];
-        }
+        // c[n] *= W8^n on the way into the second radix-4 step: W8 = h(1 -+ i), W8^2 = -+i,
+        // W8^3 = -h(1 +- i)  (upper sign forward)
+        const cf t1 = scale(c[1], h), t3 = scale(c[3], -h);
+        const cf c1 = add_rot<INV>(t1, t1), c3 = sub_rot<INV>(t3, t3);
+        const cf s02 = add_rot<INV>(c[0], c[2]), d02 = sub_rot<INV>(c[0], c[2]);
+        const cf s13 = c1 + c3, d13 = c1 - c3;
+        v[0] = b[0];
+        v[1] = s02 + s13;
+        v[2] = b[1];
+        v[3] = add_rot<INV>(d02, d13);
+        v[4] = b[2];
+        v[5] = s02 - s13;
+        v[6] = b[3];
+        v[7] = sub_rot<INV>(d02, d13);
     }
 };
 
@@ -251,15 +320,14 @@ struct WaveFft {
     }
     template <int NQ>
     static GLV_HD void split_fwd_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
+        const cf half = cf{0.5f, 0.5f};
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
             const cf a = v[q], b = m[i];
-            const cf s = {a.x + b.x, a.y - b.y};
-            const cf d = {a.x - b.x, a.y + b.y};
-            const cf tw = t.twP[q * 64 + lane];
-            const cf u = cmul(tw, d);
-            cf x = {0.5f * s.x + u.y, 0.5f * s.y - u.x};
+            const cf s = add_conj(a, b), d = sub_conj(a, b);
+            const cf u = cmul(t.twP[q * 64 + lane], d);
+            cf x = scale_subi(s, half, u);  // 0.5*s - i*u
             if (q == 0 && lane == 0) x = cf{a.x + a.y, a.x - a.y};
             v[q] = x;
         }
@@ -273,15 +341,14 @@ struct WaveFft {
     }
     template <int NQ>
     static GLV_HD void split_inv_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
+        const cf two = cf{2.0f, 2.0f};
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
             const cf a = v[q], b = m[i];
-            const cf s = {a.x + b.x, a.y - b.y};
-            const cf d = {a.x - b.x, a.y + b.y};
-            const cf tw = t.twP[q * 64 + lane];
-            const cf u = cmulc(d, tw);  // d * conj(0.5 W)
-            cf z = {s.x - 2.0f * u.y, s.y + 2.0f * u.x};
+            const cf s = add_conj(a, b), d = sub_conj(a, b);
+            const cf u = cmulc(d, t.twP[q * 64 + lane]);  // d * conj(0.5 W)
+            cf z = add_scaled_i(s, two, u);               // s + 2i*u
             if (q == 0 && lane == 0) z = cf{a.x + a.y, a.x - a.y};
             v[q] = z;
         }
