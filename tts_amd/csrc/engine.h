@@ -58,9 +58,6 @@
 #endif
 namespace glv {
 
-struct alignas(16) f4 {
-    float x, y, z, w;
-};
 
 struct RunDesc {
     int utt, t_begin, t_end, n_frames;
@@ -226,6 +223,11 @@ struct Engine {
     float sc_num, sc_den;
     Tables tab;
 
+    // this lane's window values, 16 bytes per LDS read
+    GLV_HD void load_window(cf (&w)[E]) const {
+#pragma unroll
+        for (int kp = 0; kp < E / 2; ++kp) G::load2(tab.win, kp, lane, w[2 * kp], w[2 * kp + 1]);
+    }
     GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
         lane = lane_;
         run = r;
@@ -368,9 +370,11 @@ struct Engine {
     GLV_HD void ph0_prev(const IterArgs& a, int t, cf* w) {
         finish_block(a, blkp_n, rawp, (R - 1) * HB);
         prefetch_block_prev(a, t + 1);
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const cf wn = tab.win[r * 64 + lane];
+            const cf wn = wtab[r];
             v[r] = cf{rawp[r].x * wn.x, rawp[r].y * wn.y};
         }
         shift_rows(rawp);
@@ -420,9 +424,11 @@ struct Engine {
     }
     // window one of the two arrays and start its forward transform
     GLV_HD void lin_window(const cf (&src)[E], cf* w) {
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const cf wn = tab.win[r * 64 + lane];
+            const cf wn = wtab[r];
             v[r] = cf{src[r].x * wn.x, src[r].y * wn.y};
         }
         F::fwd_a(v, tab, w, lane);
@@ -456,9 +462,11 @@ struct Engine {
     GLV_HD void ph0(const IterArgs& a, int t, cf* w) {
         finish_block(a, blk_n, raw, (R - 1) * HB);
         prefetch_block(a, t + 1);
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const cf wn = tab.win[r * 64 + lane];
+            const cf wn = wtab[r];
             v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
         }
         shift_rows(raw);
@@ -589,9 +597,11 @@ struct Engine {
     // ---- phase 6: last inverse pass, window, overlap-add, emit block t ----
     GLV_HD void ph6(const IterArgs& a, int t, const cf* r) {
         F::inv_a(v, tab, r, lane);
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            const cf wn = tab.win[q * 64 + lane];
+            const cf wn = wtab[q];
             acc[q].x = fmaf(v[q].x, wn.x, acc[q].x);
             acc[q].y = fmaf(v[q].y, wn.y, acc[q].y);
         }
@@ -666,9 +676,11 @@ struct Engine {
         // the previous spectrum and the magnitudes are not needed before phase 3: their latency
         // hides behind the forward transform
         if (WITH_SPEC) prefetch_spec(a, t);
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const cf wn = tab.win[r * 64 + lane];
+            const cf wn = wtab[r];
             v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
         }
         F::fwd_a(v, tab, w, lane);
@@ -676,9 +688,11 @@ struct Engine {
     // phase 6 of a single-frame wave: last inverse pass, window, the frame's R blocks go out
     GLV_HD void ph6_single(const IterArgs& a, int t, const cf* r) {
         F::inv_a(v, tab, r, lane);
+        cf wtab[E];
+        load_window(wtab);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            const cf wn = tab.win[q * 64 + lane];
+            const cf wn = wtab[q];
             v[q] = cf{v[q].x * wn.x, v[q].y * wn.y};
         }
         float* base = a.part_out + (int64_t)(t & (R - 1)) * a.part_stride + (int64_t)run.utt * a.y_utt_stride;

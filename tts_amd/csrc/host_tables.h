@@ -46,27 +46,27 @@ HostTables build_tables(int hop, int win_length) {
     for (int k0 = 1; k0 < 8; ++k0)
         for (int lane = 0; lane < 64; ++lane) {
             const double th = 2.0 * pi * (double)(k0 * lane) / 512.0;
-            twA[(k0 - 1) * 64 + lane] = cf{(float)cos(th), (float)-sin(th)};
+            twA[G::pair(k0, lane)] = cf{(float)cos(th), (float)-sin(th)};
         }
     for (int k1 = 1; k1 < 8; ++k1)
         for (int n0 = 0; n0 < 8; ++n0) {
             const double th = 2.0 * pi * (double)(k1 * n0) / 64.0;
-            twB[(k1 - 1) * 8 + n0] = cf{(float)cos(th), (float)-sin(th)};
+            twB[G::pair8(k1, n0)] = cf{(float)cos(th), (float)-sin(th)};
         }
     for (int i = 0; i < G::TW_C; ++i) {
         const double th = 2.0 * pi * (double)G::bin(i >> 6, i & 63) / G::P;
-        twC[i] = cf{(float)cos(th), (float)-sin(th)};
+        twC[G::pair(i >> 6, i & 63)] = cf{(float)cos(th), (float)-sin(th)};
     }
     for (int reg = 0; reg < G::E; ++reg)
         for (int lane = 0; lane < 64; ++lane) {
             const double th = 2.0 * pi * (double)G::bin(reg, lane) / G::N;
-            twP[reg * 64 + lane] = cf{(float)(0.5 * cos(th)), (float)(-0.5 * sin(th))};
+            twP[G::pair(reg, lane)] = cf{(float)(0.5 * cos(th)), (float)(-0.5 * sin(th))};
         }
     const std::vector<double> w = padded_hann(G::N, win_length);
     for (int reg = 0; reg < G::E; ++reg)
         for (int lane = 0; lane < 64; ++lane) {
             const int s = G::sample(reg, lane);
-            win[reg * 64 + lane] = cf{(float)w[s], (float)w[s + 1]};
+            win[G::pair(reg, lane)] = cf{(float)w[s], (float)w[s + 1]};
         }
     t.w2.resize(G::N);
     for (int n = 0; n < G::N; ++n) t.w2[n] = (float)(w[n] * w[n]);

@@ -43,6 +43,11 @@ struct cf {
 GLV_HD cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
 GLV_HD cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
 #endif
+// four floats moved as one 16-byte access
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
 // Complex primitives.  On the device each is written as the packed-fp32 instructions it needs,
 // with operand half selection (op_sel: which half of a source feeds the low / the high result)
 // and per-half negation: a complex product is two instructions, a sum with a rotated or
@@ -184,12 +189,32 @@ struct Geo {
     // mirror (per half h): slot = k2*64 + lane, plus row 8 holding a copy of a bin 0
     static constexpr int X3 = 9 * 64;
     static constexpr int XBUF = A * X3;  // X3 >= X1 >= X2
-    // table sizes (cf units)
-    static constexpr int TW_A = 7 * 64;             // [k0-1][lane]  W_512^(k0*lane)
-    static constexpr int TW_B = 7 * 8;              // [k1-1][n0]    W_64^(k1*n0)
+    // table sizes (cf units).  Every table is laid out in pairs of consecutive first indices:
+    // entry (k, lane) sits at pair(k, lane), so a lane's entries k and k+1 are adjacent and one
+    // 16-byte LDS read fetches both.
+    static constexpr int TW_A = 8 * 64;             // [k0][lane]    W_512^(k0*lane)  (k0 = 0 unused)
+    static constexpr int TW_B = 8 * 8;              // [k1][n0]      W_64^(k1*n0)     (k1 = 0 unused)
     static constexpr int TW_C = (A - 1) * 8 * 64;   // [k2][lane]    W_P^k, k < 512 (A = 2)
     static constexpr int TW_P = E * 64;             // [q][lane]     0.5 * W_N^bin
     static constexpr int WIN = E * 64;              // [q][lane]     (w[s], w[s+1])
+    static GLV_HD int pair(int k, int lane) { return (((k >> 1) * 64 + lane) << 1) + (k & 1); }
+    static GLV_HD int pair8(int k, int n0) { return (((k >> 1) * 8 + n0) << 1) + (k & 1); }
+    // entries 2*kp and 2*kp+1 of a lane with one 16-byte read
+    static GLV_HD void load2(const cf* table, int kp, int lane, cf& e0, cf& e1) {
+        const f4 q = reinterpret_cast<const f4*>(table)[kp * 64 + lane];
+        e0 = cf{q.x, q.y};
+        e1 = cf{q.z, q.w};
+    }
+    static GLV_HD void load2_8(const cf* table, int kp, int n0, cf& e0, cf& e1) {
+        const f4 q = reinterpret_cast<const f4*>(table)[kp * 8 + n0];
+        e0 = cf{q.x, q.y};
+        e1 = cf{q.z, q.w};
+    }
+    // a lane's 8 entries of a [k][lane] table (k0 .. k0+7, k0 even)
+    static GLV_HD void load8(const cf* table, int k0, int lane, cf (&w)[8]) {
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) load2(table, k0 / 2 + kp, lane, w[2 * kp], w[2 * kp + 1]);
+    }
     static constexpr int TABLES = TW_A + TW_B + TW_C + TW_P + WIN;
 
     // bin held by (register, lane) on the frequency side
@@ -240,8 +265,10 @@ struct WaveFft {
 #pragma unroll
             for (int n2 = 0; n2 < 8; ++n2) u[n2] = v[n2 + 8 * a];
             Dft<8, false>::run(u);
+            cf tw[8];
+            G::load8(t.twA, 0, lane, tw);
 #pragma unroll
-            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmul(u[k0], t.twA[(k0 - 1) * 64 + lane]);
+            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmul(u[k0], tw[k0]);
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) w[a * G::X1 + 72 * k0 + lane] = u[k0];
         }
@@ -254,8 +281,11 @@ struct WaveFft {
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) u[n1] = r[a * G::X1 + 72 * hi + 8 * n1 + lo];
             Dft<8, false>::run(u);
+            cf tw[8];
 #pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmul(u[k1], t.twB[(k1 - 1) * 8 + lo]);
+            for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmul(u[k1], tw[k1]);
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) v[k1 + 8 * a] = u[k1];
         }
@@ -280,9 +310,11 @@ struct WaveFft {
             for (int k2 = 0; k2 < 8; ++k2) v[k2 + 8 * a] = u[k2];
         }
         if (A == 2) {
+            cf tw[8];
+            G::load8(t.twC, 0, lane, tw);
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
-                const cf e = v[k2], o = cmul(v[k2 + 8 * (A - 1)], t.twC[k2 * 64 + lane]);
+                const cf e = v[k2], o = cmul(v[k2 + 8 * (A - 1)], tw[k2]);
                 v[k2] = e + o;
                 v[k2 + 8 * (A - 1)] = e - o;
             }
@@ -321,12 +353,16 @@ struct WaveFft {
     template <int NQ>
     static GLV_HD void split_fwd_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
         const cf half = cf{0.5f, 0.5f};
+        static_assert(NQ % 2 == 0, "table entries are fetched in pairs");
+        cf tw[NQ];
+#pragma unroll
+        for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
             const cf a = v[q], b = m[i];
             const cf s = add_conj(a, b), d = sub_conj(a, b);
-            const cf u = cmul(t.twP[q * 64 + lane], d);
+            const cf u = cmul(tw[i], d);
             cf x = scale_subi(s, half, u);  // 0.5*s - i*u
             if (q == 0 && lane == 0) x = cf{a.x + a.y, a.x - a.y};
             v[q] = x;
@@ -342,12 +378,16 @@ struct WaveFft {
     template <int NQ>
     static GLV_HD void split_inv_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
         const cf two = cf{2.0f, 2.0f};
+        static_assert(NQ % 2 == 0, "table entries are fetched in pairs");
+        cf tw[NQ];
+#pragma unroll
+        for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
             const cf a = v[q], b = m[i];
             const cf s = add_conj(a, b), d = sub_conj(a, b);
-            const cf u = cmulc(d, t.twP[q * 64 + lane]);  // d * conj(0.5 W)
+            const cf u = cmulc(d, tw[i]);                 // d * conj(0.5 W)
             cf z = add_scaled_i(s, two, u);               // s + 2i*u
             if (q == 0 && lane == 0) z = cf{a.x + a.y, a.x - a.y};
             v[q] = z;
@@ -358,11 +398,13 @@ struct WaveFft {
     // (A = 2) undo the joining butterfly: E = Z[k] + Z[k+512], O = (Z[k] - Z[k+512]) conj(W_P^k)
     static GLV_HD void inv_c(cf (&v)[E], const Tables& t, cf* w, int lane) {
         if (A == 2) {
+            cf tw[8];
+            G::load8(t.twC, 0, lane, tw);
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const cf z0 = v[k2], z1 = v[k2 + 8 * (A - 1)];
                 v[k2] = z0 + z1;
-                v[k2 + 8 * (A - 1)] = cmulc(z0 - z1, t.twC[k2 * 64 + lane]);
+                v[k2 + 8 * (A - 1)] = cmulc(z0 - z1, tw[k2]);
             }
         }
 #pragma unroll
@@ -382,8 +424,11 @@ struct WaveFft {
             cf u[8];
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) u[k1] = r[a * G::X2 + 8 * hi + k1 + 65 * lo];
+            cf tw[8];
 #pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmulc(u[k1], t.twB[(k1 - 1) * 8 + lo]);
+            for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmulc(u[k1], tw[k1]);
             Dft<8, true>::run(u);
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) v[n1 + 8 * a] = u[n1];
@@ -402,8 +447,10 @@ struct WaveFft {
             cf u[8];
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) u[k0] = r[a * G::X1 + 72 * k0 + lane];
+            cf tw[8];
+            G::load8(t.twA, 0, lane, tw);
 #pragma unroll
-            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmulc(u[k0], t.twA[(k0 - 1) * 64 + lane]);
+            for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmulc(u[k0], tw[k0]);
             Dft<8, true>::run(u);
 #pragma unroll
             for (int n2 = 0; n2 < 8; ++n2) v[n2 + 8 * a] = u[n2];
