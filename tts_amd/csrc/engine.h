@@ -223,10 +223,38 @@ struct Engine {
     float sc_num, sc_den;
     Tables tab;
 
-    // this lane's window values, 16 bytes per LDS read
-    GLV_HD void load_window(cf (&w)[E]) const {
+    // The window and the split twiddles are the same for every frame of a run: with registers
+    // to spare (n_fft 1024) a lane keeps its entries instead of reading them from LDS twice per
+    // frame - the LDS pipeline is the busiest unit of this kernel.
+#ifndef GLV_TABLES_IN_REGS
+#define GLV_TABLES_IN_REGS 1
+#endif
+    static constexpr bool kRegTab = (A == 1) && GLV_TABLES_IN_REGS;
+    cf win_r[kRegTab ? E : 1];
+    cf twp_r[kRegTab ? E : 1];
+#ifndef GLV_TWIDDLES_IN_REGS
+#define GLV_TWIDDLES_IN_REGS 0
+#endif
+    // the FFT pass twiddles as well: measured no faster (28 more registers, two waves per SIMD
+    // instead of three), so off
+    static constexpr bool kRegTw = kRegTab && GLV_TWIDDLES_IN_REGS;
+    cf twa_r[kRegTw ? 8 : 1];
+    cf twb_r[kRegTw ? 8 : 1];
+    GLV_HD const cf* twa_regs() const { return kRegTw ? twa_r : nullptr; }
+    GLV_HD const cf* twb_regs() const { return kRegTw ? twb_r : nullptr; }
+    GLV_HD const cf* twp_regs() const { return kRegTab ? twp_r : nullptr; }
+    GLV_HD void load_window_lds(cf (&w)[E]) const {
 #pragma unroll
         for (int kp = 0; kp < E / 2; ++kp) G::load2(tab.win, kp, lane, w[2 * kp], w[2 * kp + 1]);
+    }
+    // this lane's window values
+    GLV_HD void load_window(cf (&w)[E]) const {
+        if (kRegTab) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) w[q] = win_r[q];
+        } else {
+            load_window_lds(w);
+        }
     }
     GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
         lane = lane_;
@@ -237,6 +265,30 @@ struct Engine {
         tab.twP = tab.twC + G::TW_C;
         tab.win = tab.twP + G::TW_P;
         mbase = G::mirror_base(lane);
+        if (kRegTw) {
+            cf ta[8], tb[8];
+            G::load8(tab.twA, 0, lane, ta);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) G::load2_8(tab.twB, kp, lane & 7, tb[2 * kp], tb[2 * kp + 1]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                twa_r[k % (kRegTw ? 8 : 1)] = ta[k];
+                twb_r[k % (kRegTw ? 8 : 1)] = tb[k];
+            }
+        }
+        if (kRegTab) {
+            cf w[E];
+            load_window_lds(w);
+#pragma unroll
+            for (int q = 0; q < E; ++q) win_r[q] = w[q];
+#pragma unroll
+            for (int kp = 0; kp < E / 2; ++kp) {
+                cf e0, e1;
+                G::load2(tab.twP, kp, lane, e0, e1);
+                twp_r[(2 * kp) % (kRegTab ? E : 1)] = e0;
+                twp_r[(2 * kp + 1) % (kRegTab ? E : 1)] = e1;
+            }
+        }
 #pragma unroll
         for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
         sc_num = 0.f;
@@ -378,13 +430,13 @@ struct Engine {
             v[r] = cf{rawp[r].x * wn.x, rawp[r].y * wn.y};
         }
         shift_rows(rawp);
-        F::fwd_a(v, tab, w, lane);
+        F::fwd_a(v, tab, w, lane, twa_regs());
     }
     // finishes the previous signal's frame: its spectrum is the momentum term's tprev
     GLV_HD void ph3_prev(const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
-        F::split_fwd(v, m, tab, lane);
+        F::split_fwd(v, m, tab, lane, twp_regs());
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) tp_n[reg] = v[reg];
     }
@@ -431,7 +483,7 @@ struct Engine {
             const cf wn = wtab[r];
             v[r] = cf{src[r].x * wn.x, src[r].y * wn.y};
         }
-        F::fwd_a(v, tab, w, lane);
+        F::fwd_a(v, tab, w, lane, twa_regs());
     }
     GLV_HD void lin_window_signal(cf* w) { lin_window(rawp, w); }
     GLV_HD void lin_window_combined(cf* w) { lin_window(raw, w); }
@@ -444,7 +496,7 @@ struct Engine {
     GLV_HD void ph3_metric(const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
-        F::split_fwd(v, m, tab, lane);
+        F::split_fwd(v, m, tab, lane, twp_regs());
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) {
             const cf x = v[reg];
@@ -470,9 +522,9 @@ struct Engine {
             v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
         }
         shift_rows(raw);
-        F::fwd_a(v, tab, w, lane);
+        F::fwd_a(v, tab, w, lane, twa_regs());
     }
-    GLV_HD void ph1_read(const cf* r) { F::fwd_b(v, tab, r, lane); }
+    GLV_HD void ph1_read(const cf* r) { F::fwd_b(v, tab, r, lane, twb_regs()); }
     GLV_HD void ph1_write(cf* w) { F::fwd_b_store(v, w, lane); }
     GLV_HD void ph2_read(const cf* r) { F::fwd_c(v, tab, r, lane); }
     GLV_HD void ph2_write(cf* w) { F::mirror_store(v, w, lane); }
@@ -485,7 +537,7 @@ struct Engine {
     GLV_HD void ph3_stft(const IterArgs& a, int t, const cf* r) {
         cf m[E];
         F::mirror_load(m, r, mbase);
-        F::split_fwd(v, m, tab, lane);
+        F::split_fwd(v, m, tab, lane, twp_regs());
         store_spec(a, t);
     }
     // registers q0 .. q0+nq-1 (q0, nq even) of a native frame
@@ -523,7 +575,7 @@ struct Engine {
             cf m[CH];
             F::template mirror_load_part<CH>(m, r, mbase, q0);
             if (RC == 0 && !kPrefetchTp) load_spec(a, t, tp_n, q0, CH);
-            F::template split_fwd_part<CH>(v, m, tab, lane, q0);  // v = rebuilt frame
+            F::template split_fwd_part<CH>(v, m, tab, lane, q0, twp_regs());  // v = rebuilt frame
             if (RC == 0) store_spec(a, t, q0, CH);
 #pragma unroll
             for (int reg = q0; reg < q0 + CH; ++reg) {
@@ -586,17 +638,17 @@ struct Engine {
         for (int q0 = 0; q0 < E; q0 += CH) {
             cf m[CH];
             F::template mirror_load_part<CH>(m, r, mbase, q0);
-            F::template split_inv_part<CH>(v, m, tab, lane, q0);
+            F::template split_inv_part<CH>(v, m, tab, lane, q0, twp_regs());
             if (CH < E) GLV_SCHED_FENCE();
         }
         F::inv_c(v, tab, w, lane);
     }
-    GLV_HD void ph5_read(const cf* r) { F::inv_b(v, tab, r, lane); }
+    GLV_HD void ph5_read(const cf* r) { F::inv_b(v, tab, r, lane, twb_regs()); }
     GLV_HD void ph5_write(cf* w) { F::inv_b_store(v, w, lane); }
 
     // ---- phase 6: last inverse pass, window, overlap-add, emit block t ----
     GLV_HD void ph6(const IterArgs& a, int t, const cf* r) {
-        F::inv_a(v, tab, r, lane);
+        F::inv_a(v, tab, r, lane, twa_regs());
         cf wtab[E];
         load_window(wtab);
 #pragma unroll
@@ -683,11 +735,11 @@ struct Engine {
             const cf wn = wtab[r];
             v[r] = cf{raw[r].x * wn.x, raw[r].y * wn.y};
         }
-        F::fwd_a(v, tab, w, lane);
+        F::fwd_a(v, tab, w, lane, twa_regs());
     }
     // phase 6 of a single-frame wave: last inverse pass, window, the frame's R blocks go out
     GLV_HD void ph6_single(const IterArgs& a, int t, const cf* r) {
-        F::inv_a(v, tab, r, lane);
+        F::inv_a(v, tab, r, lane, twa_regs());
         cf wtab[E];
         load_window(wtab);
 #pragma unroll

@@ -257,8 +257,9 @@ struct WaveFft {
     using G = Geo<A>;
     static constexpr int E = G::E;
 
+    // (twr: the lane's 8 twiddles of the pass where the caller keeps them in registers, else null)
     // ---- forward: A interleaved 512-point transforms ----
-    static GLV_HD void fwd_a(cf (&v)[E], const Tables& t, cf* w, int lane) {
+    static GLV_HD void fwd_a(cf (&v)[E], const Tables& t, cf* w, int lane, const cf* twr = nullptr) {
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
@@ -266,14 +267,19 @@ struct WaveFft {
             for (int n2 = 0; n2 < 8; ++n2) u[n2] = v[n2 + 8 * a];
             Dft<8, false>::run(u);
             cf tw[8];
-            G::load8(t.twA, 0, lane, tw);
+            if (twr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tw[k] = twr[k];
+            } else {
+                G::load8(t.twA, 0, lane, tw);
+            }
 #pragma unroll
             for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmul(u[k0], tw[k0]);
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) w[a * G::X1 + 72 * k0 + lane] = u[k0];
         }
     }
-    static GLV_HD void fwd_b(cf (&v)[E], const Tables& t, const cf* r, int lane) {
+    static GLV_HD void fwd_b(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
         const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
@@ -282,8 +288,13 @@ struct WaveFft {
             for (int n1 = 0; n1 < 8; ++n1) u[n1] = r[a * G::X1 + 72 * hi + 8 * n1 + lo];
             Dft<8, false>::run(u);
             cf tw[8];
+            if (twr) {
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+                for (int k = 0; k < 8; ++k) tw[k] = twr[k];
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+            }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmul(u[k1], tw[k1]);
 #pragma unroll
@@ -347,16 +358,23 @@ struct WaveFft {
     // ---- real <-> half-complex split ----
     // X[k] = 0.5*(Zk + conj Zm) - i * (0.5 W_N^k) * (Zk - conj Zm); bin 0 packs
     // (DC, Nyquist) = (Re Z0 + Im Z0, Re Z0 - Im Z0).
-    static GLV_HD void split_fwd(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane) {
-        split_fwd_part<E>(v, m, t, lane, 0);
+    // (twp: this lane's E entries of the twP table if the caller keeps them in registers, else null)
+    static GLV_HD void split_fwd(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane, const cf* twp = nullptr) {
+        split_fwd_part<E>(v, m, t, lane, 0, twp);
     }
     template <int NQ>
-    static GLV_HD void split_fwd_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
+    static GLV_HD void split_fwd_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0,
+                                      const cf* twp = nullptr) {
         const cf half = cf{0.5f, 0.5f};
         static_assert(NQ % 2 == 0, "table entries are fetched in pairs");
         cf tw[NQ];
+        if (twp) {
 #pragma unroll
-        for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
+            for (int i = 0; i < NQ; ++i) tw[i] = twp[q0 + i];
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
+        }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
@@ -372,16 +390,22 @@ struct WaveFft {
     // so the second term is doubled); bin 0: (DC + Nyq, DC - Nyq).
     // The result is 2x the half-size spectrum; callers fold the factor into the
     // 1/N of the inverse transform.
-    static GLV_HD void split_inv(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane) {
-        split_inv_part<E>(v, m, t, lane, 0);
+    static GLV_HD void split_inv(cf (&v)[E], const cf (&m)[E], const Tables& t, int lane, const cf* twp = nullptr) {
+        split_inv_part<E>(v, m, t, lane, 0, twp);
     }
     template <int NQ>
-    static GLV_HD void split_inv_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0) {
+    static GLV_HD void split_inv_part(cf (&v)[E], const cf (&m)[NQ], const Tables& t, int lane, int q0,
+                                      const cf* twp = nullptr) {
         const cf two = cf{2.0f, 2.0f};
         static_assert(NQ % 2 == 0, "table entries are fetched in pairs");
         cf tw[NQ];
+        if (twp) {
 #pragma unroll
-        for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
+            for (int i = 0; i < NQ; ++i) tw[i] = twp[q0 + i];
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < NQ / 2; ++kp) G::load2(t.twP, q0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
+        }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = q0 + i;
@@ -417,7 +441,7 @@ struct WaveFft {
             for (int n0 = 0; n0 < 8; ++n0) w[a * G::X2 + lane + 65 * n0] = u[n0];
         }
     }
-    static GLV_HD void inv_b(cf (&v)[E], const Tables& t, const cf* r, int lane) {
+    static GLV_HD void inv_b(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
         const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
@@ -425,8 +449,13 @@ struct WaveFft {
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) u[k1] = r[a * G::X2 + 8 * hi + k1 + 65 * lo];
             cf tw[8];
+            if (twr) {
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+                for (int k = 0; k < 8; ++k) tw[k] = twr[k];
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) G::load2_8(t.twB, kp, lo, tw[2 * kp], tw[2 * kp + 1]);
+            }
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) u[k1] = cmulc(u[k1], tw[k1]);
             Dft<8, true>::run(u);
@@ -441,14 +470,19 @@ struct WaveFft {
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) w[a * G::X1 + 72 * hi + 8 * n1 + lo] = v[n1 + 8 * a];
     }
-    static GLV_HD void inv_a(cf (&v)[E], const Tables& t, const cf* r, int lane) {
+    static GLV_HD void inv_a(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) u[k0] = r[a * G::X1 + 72 * k0 + lane];
             cf tw[8];
-            G::load8(t.twA, 0, lane, tw);
+            if (twr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tw[k] = twr[k];
+            } else {
+                G::load8(t.twA, 0, lane, tw);
+            }
 #pragma unroll
             for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmulc(u[k0], tw[k0]);
             Dft<8, true>::run(u);
