@@ -22,6 +22,7 @@ run bench_b8 200 --no-cpu --batch 8
 run bench_single_ref_utterance 200 --no-cpu --batch 1 --n-fft 2048 --frames 865 --steps 50 --warmup 5
 run ablation_traffic_only 200 --no-cpu --traffic-only
 run ablation_compute_only 200 --no-cpu --alias-utts
+run ablation_spectral_momentum 200 --no-cpu --linear 0
 run ablation_recompute 200 --no-cpu --recompute 1
 run ablation_n2048_traffic_only 200 --no-cpu --n-fft 2048 --frames 865 --traffic-only
 run ablation_n2048_compute_only 200 --no-cpu --n-fft 2048 --frames 865 --alias-utts
