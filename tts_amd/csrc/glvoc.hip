@@ -965,7 +965,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     p->shard_k = 0;
     p->shard_active = true;
     // halo regions nobody writes on the outermost shards must read as zero
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         HIP_TRY(hipMemsetAsync(p->d_ym[i], 0, sizeof(float) * p->blocks * p->hop, st));
         HIP_TRY(hipMemsetAsync(p->d_yt[i], 0, sizeof(float) * p->blocks * p->hop, st));
     }
@@ -989,9 +989,21 @@ extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
     IterArgs a = shard_iter_args(p);
     a.cmom = momentum / (1.0f + momentum);
     a.has_prev = p->shard_k > 0;
-    shard_set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
-    HIP_TRY(p->launch_engine(MODE_ITER, false, a, engine_grid(p), (hipStream_t)stream));
-    p->shard_cur ^= 1;
+    if (p->linear) {
+        // momentum in the time domain: the halo swap has completed both older generations, so
+        // the previous signal is as local as the current one
+        const int cur = p->shard_cur, out = (cur + 1) % 3, prev = p->shard_k == 0 ? cur : (cur + 2) % 3;
+        const int64_t off = (int64_t)p->shard_t0 * p->hop;
+        shard_set_io(p, a, cur, out);
+        a.y_prev = p->d_ym[prev] - off;
+        a.y_prev_tail = p->d_yt[prev] - off;
+        HIP_TRY(p->launch_engine(MODE_ITER_LIN, false, a, engine_grid(p), (hipStream_t)stream));
+        p->shard_cur = out;
+    } else {
+        shard_set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
+        HIP_TRY(p->launch_engine(MODE_ITER, false, a, engine_grid(p), (hipStream_t)stream));
+        p->shard_cur ^= 1;
+    }
     p->shard_k++;
     return GLV_OK;
 }
