@@ -180,7 +180,7 @@ int engine_blocks_per_cu_t() {
     using G = Geo<A>;
     const size_t lds = (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER, false>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN, false>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess)
         n = 1;
     return n < 1 ? 1 : n;
@@ -341,11 +341,8 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         const int64_t slots = p->wave_slots;
         const int64_t rounds = std::max<int64_t>(1, (total + slots * 64 - 1) / (slots * 64));
         const int64_t cap = slots * rounds;
-        int fpr = (int)std::max<int64_t>(std::max(1, p->R - 1), (total + cap - 1) / cap);
-        for (;; ++fpr) {
-            runs = build_runs(n_frames_host, batch, fpr, p->R);
-            if ((int64_t)runs.size() <= cap || fpr >= max_t) break;
-        }
+        runs = build_runs_target(n_frames_host, batch, cap, p->R);
+        (void)max_t;
     }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
     std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);

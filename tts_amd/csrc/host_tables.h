@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "engine.h"
@@ -124,6 +125,40 @@ inline std::vector<RunDesc> build_runs(const int* n_frames, int batch, int frame
         nr = std::max(1, std::min(nr, T / min_len));
         for (int i = 0; i < nr; ++i) {
             const int t0 = (int)((int64_t)i * T / nr), t1 = (int)((int64_t)(i + 1) * T / nr);
+            runs.push_back(RunDesc{b, t0, t1, T});
+        }
+    }
+    return runs;
+}
+
+// The same with the NUMBER of runs given: `target` runs are dealt to the utterances in
+// proportion to their frames (largest remainders first), so that a launch can fill a whole
+// number of wave slots.  An utterance still gets at most T / (R-1) runs and at least one.
+inline std::vector<RunDesc> build_runs_target(const int* n_frames, int batch, int64_t target, int R) {
+    int64_t total = 0;
+    for (int b = 0; b < batch; ++b) total += std::max(0, n_frames[b]);
+    const int min_len = std::max(1, R - 1);
+    std::vector<int> nr(batch, 0);
+    std::vector<std::pair<double, int>> rest;
+    int64_t given = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int T = n_frames[b];
+        if (T <= 0) continue;
+        const double share = total > 0 ? (double)target * T / (double)total : 1.0;
+        const int cap = std::max(1, T / min_len);
+        nr[b] = std::max(1, std::min((int)share, cap));
+        given += nr[b];
+        if (nr[b] < cap) rest.push_back({share - (int)share, b});
+    }
+    std::sort(rest.begin(), rest.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) {
+        return x.first != y.first ? x.first > y.first : x.second < y.second;
+    });
+    for (size_t i = 0; i < rest.size() && given < target; ++i, ++given) nr[rest[i].second]++;
+    std::vector<RunDesc> runs;
+    for (int b = 0; b < batch; ++b) {
+        const int T = n_frames[b];
+        for (int i = 0; i < nr[b]; ++i) {
+            const int t0 = (int)((int64_t)i * T / nr[b]), t1 = (int)((int64_t)(i + 1) * T / nr[b]);
             runs.push_back(RunDesc{b, t0, t1, T});
         }
     }
