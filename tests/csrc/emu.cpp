@@ -392,6 +392,19 @@ void emu_counter_uniform(uint64_t seed, uint64_t idx0, int n, float* u) {
     for (int i = 0; i < n; ++i) u[i] = counter_uniform(seed, idx0 + (uint64_t)i);
 }
 
+// the run table of build_runs_target: fills out[4*i .. 4*i+3] = utt, t_begin, t_end, n_frames;
+// returns the number of runs (at most max_out are written)
+int emu_runs_target(const int* n_frames, int batch, int64_t target, int R, int* out, int max_out) {
+    const std::vector<RunDesc> runs = build_runs_target(n_frames, batch, target, R);
+    for (size_t i = 0; i < runs.size() && (int)i < max_out; ++i) {
+        out[4 * i] = runs[i].utt;
+        out[4 * i + 1] = runs[i].t_begin;
+        out[4 * i + 2] = runs[i].t_end;
+        out[4 * i + 3] = runs[i].n_frames;
+    }
+    return (int)runs.size();
+}
+
 int emu_stft(int n_fft, int hop, int win_length, const float* y, int64_t y_stride, const int* n_frames,
              int batch, int frames_stride, int frames_per_run, float* D) {
     return dispatch(n_fft, hop, [&](auto* tag) {

@@ -232,3 +232,30 @@ def test_time_domain_momentum_drift_on_the_fixture(emu, lj001):
     y, sc = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [430], 1024, 256, 1024, 16, 14, recompute=3)
     assert rel_l2(y[0], snaps[16]) < 2e-4
     assert np.max(np.abs(sc[0] - sc_ref) / sc_ref) < 1e-5
+
+
+@pytest.mark.parametrize("lens,target,r", [([430] * 64, 3072, 4), ([430] * 64, 4096, 4), ([865] * 64, 2048, 8),
+                                           ([97, 3, 640, 12, 2, 311], 100, 4), ([5, 5, 5], 64, 4),
+                                           ([865], 2048, 8), ([2, 2], 1, 2)])
+def test_run_table_with_a_given_number_of_runs(emu, lens, target, r):
+    """Runs are dealt in proportion to the frames: exactly `target` of them when every utterance
+    can be cut that often, never shorter than R-1 frames (unless the utterance is), contiguous
+    and complete."""
+    nf = np.asarray(lens, np.int32)
+    out = np.zeros((max(target, len(lens)) * 2 + 8, 4), np.int32)
+    n = emu.emu_runs_target(nf.ctypes.data_as(ip), len(lens), ctypes.c_int64(target), r,
+                            out.ctypes.data_as(ip), len(out))
+    runs = out[:n]
+    most = sum(max(1, t // max(1, r - 1)) for t in lens)
+    assert min(target, most) <= n <= min(most, target + len(lens))
+    if most >= target >= len(lens) and len(set(lens)) == 1:
+        assert n == target
+    for b, t in enumerate(lens):
+        mine = runs[runs[:, 0] == b]
+        assert mine[0, 1] == 0 and mine[-1, 2] == t and np.all(mine[1:, 1] == mine[:-1, 2])
+        assert np.all(mine[:, 3] == t)
+        if len(mine) > 1:
+            assert np.all(mine[:, 2] - mine[:, 1] >= r - 1)
+    sizes = runs[:, 2] - runs[:, 1]
+    if len(set(lens)) == 1 and n == target:
+        assert sizes.max() - sizes.min() <= 1

@@ -153,7 +153,17 @@ inline std::vector<RunDesc> build_runs_target(const int* n_frames, int batch, in
     std::sort(rest.begin(), rest.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) {
         return x.first != y.first ? x.first > y.first : x.second < y.second;
     });
-    for (size_t i = 0; i < rest.size() && given < target; ++i, ++given) nr[rest[i].second]++;
+    // one more run each, largest remainders first; again while utterances with room are left
+    for (bool any = true; any && given < target;) {
+        any = false;
+        for (size_t i = 0; i < rest.size() && given < target; ++i) {
+            const int b = rest[i].second;
+            if (nr[b] >= std::max(1, n_frames[b] / min_len)) continue;
+            nr[b]++;
+            given++;
+            any = true;
+        }
+    }
     std::vector<RunDesc> runs;
     for (int b = 0; b < batch; ++b) {
         const int T = n_frames[b];
