@@ -18,6 +18,8 @@ run bench_unfused 200 --no-cpu --unfused
 run bench_ljspeech_lengths 200 --no-cpu --lengths ljspeech
 run bench_n2048_t865 200 --no-cpu --n-fft 2048 --frames 865
 run bench_b4096 300 --no-cpu --batch 4096 --steps 3 --warmup 1
+run bench_b128 200 --no-cpu --batch 128
+run bench_b32 200 --no-cpu --batch 32
 run bench_b8 200 --no-cpu --batch 8
 run bench_single_ref_utterance 200 --no-cpu --batch 1 --n-fft 2048 --frames 865 --steps 50 --warmup 5
 run ablation_traffic_only 200 --no-cpu --traffic-only

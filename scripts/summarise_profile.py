@@ -17,7 +17,7 @@ from collections import defaultdict
 
 def find(outdir, sub, suffix):
     hits = glob.glob(os.path.join(outdir, sub, "**", f"*{suffix}"), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None   # the newest, if older runs share the directory
 
 
 def short(name):
@@ -49,6 +49,20 @@ def main():
                              f"{float(row['MinNs'])/1e3:.2f} | {float(row['MaxNs'])/1e3:.2f} | {float(row['Percentage']):.2f} |")
                 summary.setdefault("kernels", {})[name] = {"calls": int(row["Calls"]), "avg_us": avg_us}
         lines.append("")
+    # the bench line printed by the profiled process itself: its HIP-event time per launch of
+    # the iteration kernel, to set beside the profiler's average for the same launches
+    log = os.path.join(outdir, "kt.log")
+    if os.path.exists(log):
+        for text in open(log, errors="replace"):
+            if text.startswith("{") and '"roofline"' in text:
+                roof = json.loads(text)["roofline"]
+                summary["bench_under_profiler_us_per_launch"] = roof["kernel_ms_per_launch"] * 1e3
+                lines += ["## the profiled process's own measurement", "",
+                          f"HIP events around the {roof['kernel']} launches, in the same process the table above was "
+                          f"taken from: {roof['kernel_ms_per_launch'] * 1e3:.2f} us per launch (kernel-trace serialises "
+                          "dispatches and times each one from its own start to its own end, so it reads a few "
+                          "percent above the back-to-back figure; without the profiler the same events give the "
+                          "bench line's value).", ""]
     per = {}
     for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         path = find(outdir, sub, "counter_collection.csv")
