@@ -1231,3 +1231,11 @@ extern "C" int glv_istft(glv_plan* p, const float* D_dev, const int* n_frames_ho
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }
+
+#ifdef GLV_WAVE_TIMES
+// measurement build only: copies the time stamps of the last iteration launch to the host
+extern "C" int glv_debug_wave_times(unsigned long long* out, int n_waves) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(glv_wave_times), sizeof(unsigned long long) * 20 * n_waves) == hipSuccess ? 0 : -1;
+}
+#endif

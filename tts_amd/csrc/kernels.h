@@ -28,6 +28,12 @@ namespace {
 #endif
 constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 
+// wave priority inside the frame loop (the SIMD issues oldest-first among equal priorities):
+// 0 none, 1 falling with the wave's progress, 2 rotating per frame, 3 alternating per frame
+#ifndef GLV_PRIO
+#define GLV_PRIO 1
+#endif
+
 __device__ __forceinline__ void wave_sync() {
     // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
     // One wave's DS operations execute in issue order, so no counter wait is needed;
@@ -44,6 +50,18 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef GLV_MIN_WAVES_A2
 #define GLV_MIN_WAVES_A2 2
 #endif
+#ifdef GLV_WAVE_TIMES
+// measurement build: every wave of the iteration kernel leaves four time stamps (100 MHz clock)
+__device__ unsigned long long glv_wave_times[20 * 16384];
+#define GLV_STAMP(k)                                                                          \
+    if (MODE == MODE_ITER_LIN && (threadIdx.x & 63) == 0) {                                   \
+        const int w_ = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);                      \
+        if (w_ < 16384 && (k) < 20) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
+    }
+#else
+#define GLV_STAMP(k)
+#endif
+
 template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
@@ -51,6 +69,7 @@ gl_engine_kernel(IterArgs a) {
     using Eng = Engine<A, HB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tables = reinterpret_cast<cf*>(smem);
+    GLV_STAMP(0)
     {
         // stage the tables: all of a thread's loads are issued before the first is stored, so
         // the block pays one memory latency, not one per round
@@ -72,6 +91,7 @@ gl_engine_kernel(IterArgs a) {
         }
     }
     __syncthreads();
+    GLV_STAMP(1)
 
     // wave-uniform values are forced into scalar registers: the compiler cannot see that
     // threadIdx.x >> 6 (and everything loaded through it) is the same in all 64 lanes
@@ -135,7 +155,31 @@ gl_engine_kernel(IterArgs a) {
     }
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     if (kRc) e.prefetch_s(a, e.run.t_begin);
+    GLV_STAMP(2)
+#if GLV_PRIO == 1
+    const int prio_n = e.run.t_end - e.run.t_begin;
+    const int prio_q1 = e.run.t_begin + ((prio_n + 3) >> 2), prio_q2 = e.run.t_begin + ((2 * prio_n + 3) >> 2),
+              prio_q3 = e.run.t_begin + ((3 * prio_n + 3) >> 2);
+#endif
+#if GLV_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int t = e.run.t_begin; !kSingle && t < e.run.t_end; ++t) {
+#if GLV_PRIO == 1
+        if (t == prio_q1) __builtin_amdgcn_s_setprio(2);
+        else if (t == prio_q2) __builtin_amdgcn_s_setprio(1);
+        else if (t == prio_q3) __builtin_amdgcn_s_setprio(0);
+#elif GLV_PRIO == 2
+        switch ((t - e.run.t_begin + (int)(blockIdx.x >> 8)) % 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(2); break;
+        }
+#elif GLV_PRIO == 3
+        if ((t - e.run.t_begin) & 1) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(1);
+#endif
+        GLV_STAMP(4 + t - e.run.t_begin)
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
             continue;
@@ -218,6 +262,7 @@ gl_engine_kernel(IterArgs a) {
         wave_sync();
     }
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
+    GLV_STAMP(3)
     if (SC) {
         float num = e.sc_num, den = e.sc_den;
 #pragma unroll
