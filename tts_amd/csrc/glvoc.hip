@@ -128,7 +128,7 @@ struct glv_plan {
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
     void (*launch_power)(const ElemArgs&, const cf*, float*, hipStream_t) = nullptr;
     hipError_t (*launch_mel_native)(const glv_plan*, const ElemArgs&, const float*, float, float, const cf*,
-                                    uint64_t, float, hipStream_t) = nullptr;
+                                    uint64_t, float, unsigned*, hipStream_t) = nullptr;
 };
 
 namespace {
@@ -221,12 +221,13 @@ void launch_power_t(const ElemArgs& ea, const cf* spec, float* power, hipStream_
 
 template <int A>
 hipError_t launch_mel_native_t(const glv_plan* p, const ElemArgs& ea, const float* mel_db, float mean,
-                               float std_, const cf* phase, uint64_t seed, float inv_n, hipStream_t st) {
+                               float std_, const cf* phase, uint64_t seed, float inv_n, unsigned* peak_bits,
+                               hipStream_t st) {
     const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
     const size_t lds = (size_t)(32 * (p->Mp + 1) + 32 * kMelTileStride + 32) * sizeof(float);
     hipLaunchKernelGGL((mel_native_kernel<A>), dim3((unsigned)((rows + 31) / 32)), dim3(64 * kMelWaves), lds, st, ea,
                        mel_db, p->d_pinv_t, p->n_mels, p->Mp, p->Fp, mean, std_, phase, seed, inv_n, p->d_S,
-                       p->d_spec);
+                       p->d_spec, peak_bits);
     return hipGetLastError();
 }
 
@@ -768,7 +769,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(p->launch_mel_native(p, ea, src.mel_db_dev, src.mean, src.std_,
-                                     reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, st));
+                                     reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, peak_bits, st));
     }
 
     // inverse = istft(angles) of the initial phase
@@ -869,7 +870,6 @@ extern "C" int glv_mel_to_audio(glv_plan* p, const float* mel_db_dev, float mean
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
     const bool normalise = peak_eps >= 0.f;
-    if (normalise) HIP_TRY(hipMemsetAsync(p->d_peak, 0, sizeof(unsigned) * batch, st));
     MagnitudeSource src;
     src.mel_db_dev = mel_db_dev;
     src.mean = mean;
@@ -877,11 +877,14 @@ extern "C" int glv_mel_to_audio(glv_plan* p, const float* mel_db_dev, float mean
     int rc = griffinlim_impl(p, src, phase0_dev, seed, n_frames_host, batch, frames_stride, n_iter, momentum,
                              y_dev, y_stride, sc_curve_dev, normalise ? p->d_peak : nullptr, stream);
     if (rc != GLV_OK || !normalise) return rc;
-    // n_samples[b] = hop * (n_frames[b] - 1)
-    std::vector<int> n_samples(batch);
-    for (int b = 0; b < batch; ++b) n_samples[b] = p->hop * (n_frames_host[b] - 1);
-    return glv_peak_scale(p, y_dev, n_samples.data(), batch, y_stride, reinterpret_cast<const float*>(p->d_peak),
-                          peak_eps, stream);
+    // n_samples[b] = hop * (n_frames[b] - 1), from the frame counts already on the device
+    int max_t = 0;
+    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
+    const int64_t max_len = std::max<int64_t>(1, (int64_t)p->hop * (max_t - 1));
+    hipLaunchKernelGGL(peak_scale_kernel, dim3(std::min<unsigned>(grid_for(max_len, 256 * 8), 64), batch), dim3(256),
+                       0, st, y_dev, y_stride, p->d_nframes, p->d_peak, peak_eps, p->hop);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
 }
 
 
@@ -1121,7 +1124,7 @@ extern "C" int glv_peak_scale(glv_plan* p, float* y_dev, const int* n_samples_ho
     int rc = peak_prepare(p, n_samples_host, batch, y_stride, st, &grid);
     if (rc != GLV_OK) return rc;
     hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, p->d_nsamples,
-                       reinterpret_cast<const unsigned*>(peak_dev), eps);
+                       reinterpret_cast<const unsigned*>(peak_dev), eps, 0);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
 }

@@ -394,10 +394,11 @@ __global__ __launch_bounds__(256) void peak_reduce_kernel(const float* y, int64_
     }
 }
 
+// lengths: n_samples[b], or hop * (n_frames[b] - 1) when `hop` > 0 and `n_samples` holds frame counts
 __global__ void peak_scale_kernel(float* y, int64_t y_stride, const int* n_samples,
-                                  const unsigned* peak_bits, float eps) {
+                                  const unsigned* peak_bits, float eps, int hop) {
     const int b = blockIdx.y;
-    const int64_t len = n_samples[b];
+    const int64_t len = hop > 0 ? (int64_t)hop * (n_samples[b] - 1) : n_samples[b];
     const float denom = __uint_as_float(peak_bits[b]) + eps;
     for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
          n += (int64_t)gridDim.x * blockDim.x) {
@@ -504,8 +505,12 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
                                                          const float* __restrict__ Wt, int M, int Mp, int Fp,
                                                          float mean, float std_, const cf* phase_nat,
                                                          uint64_t seed, float inv_n, float* S_native,
-                                                         cf* spec) {
+                                                         cf* spec, unsigned* peak_bits) {
     extern __shared__ float mel_smem[];
+    // the per-utterance maxima the finalising kernel gathers start at zero (a memset of its
+    // own would cost a gap in the stream)
+    if (peak_bits && blockIdx.x == 0)
+        for (int b = threadIdx.x; b < ea.batch; b += 64 * kMelWaves) peak_bits[b] = 0u;
     const int lds = Mp + 1;
     float* sa = mel_smem;                          // [32][Mp + 1] mel power of this block's frames
     float* tile = sa + 32 * lds;               // [32][kMelTileStride] magnitudes of one half
