@@ -28,8 +28,10 @@ namespace {
 #endif
 constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 
-// wave priority inside the frame loop (the SIMD issues oldest-first among equal priorities):
-// 0 none, 1 falling with the wave's progress, 2 rotating per frame, 3 alternating per frame
+// Wave priority inside the frame loop.  A SIMD issues from its oldest wave first, so without
+// help the waves of a SIMD finish one after the other and the last runs alone.  1: a wave's
+// priority falls after each third of its run and again for its last frame, which lets the
+// waves behind catch up and all of them end together.  0: priorities untouched.
 #ifndef GLV_PRIO
 #define GLV_PRIO 1
 #endif
@@ -158,10 +160,8 @@ gl_engine_kernel(IterArgs a) {
     GLV_STAMP(2)
 #if GLV_PRIO == 1
     const int prio_n = e.run.t_end - e.run.t_begin;
-    const int prio_q1 = e.run.t_begin + ((prio_n + 3) >> 2), prio_q2 = e.run.t_begin + ((2 * prio_n + 3) >> 2),
-              prio_q3 = e.run.t_begin + ((3 * prio_n + 3) >> 2);
-#endif
-#if GLV_PRIO == 1
+    const int prio_q1 = e.run.t_begin + (prio_n + 2) / 3, prio_q2 = e.run.t_begin + (2 * prio_n + 2) / 3,
+              prio_q3 = e.run.t_end - 1;
     __builtin_amdgcn_s_setprio(3);
 #endif
     for (int t = e.run.t_begin; !kSingle && t < e.run.t_end; ++t) {
@@ -169,15 +169,6 @@ gl_engine_kernel(IterArgs a) {
         if (t == prio_q1) __builtin_amdgcn_s_setprio(2);
         else if (t == prio_q2) __builtin_amdgcn_s_setprio(1);
         else if (t == prio_q3) __builtin_amdgcn_s_setprio(0);
-#elif GLV_PRIO == 2
-        switch ((t - e.run.t_begin + (int)(blockIdx.x >> 8)) % 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(2); break;
-        }
-#elif GLV_PRIO == 3
-        if ((t - e.run.t_begin) & 1) __builtin_amdgcn_s_setprio(0);
-        else __builtin_amdgcn_s_setprio(1);
 #endif
         GLV_STAMP(4 + t - e.run.t_begin)
         if (MODE == MODE_TRAFFIC) {
