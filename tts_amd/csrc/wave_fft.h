@@ -252,6 +252,56 @@ struct Tables {
 // The phases of the transform between LDS exchanges.  `w` = buffer this phase writes, `r` =
 // buffer it reads (the same buffer on the device; the host emulation alternates two).
 // ---------------------------------------------------------------------------
+// The transposes between the first and the second pass swap a lane's register index with the
+// high digit (bits 3..5) of its lane number and leave the low digit alone.  GLV_XCHG_REGS = 1
+// does that without LDS: lane bit 5 with v_permlane32_swap, bit 4 with v_permlane16_swap, bit 3
+// with a row rotation by 8 under a bank mask (device code only; the host emulation keeps the
+// LDS form, which defines the result).
+#ifndef GLV_XCHG_REGS
+#define GLV_XCHG_REGS 1
+#endif
+#if GLV_XCHG_REGS && defined(__HIP_DEVICE_COMPILE__)
+#define GLV_XCHG_REGS_DEVICE 1
+typedef unsigned glv_u2 __attribute__((ext_vector_type(2)));
+// (x: register with the index bit clear, y: with it set) <-> lane bit 5 / 4 / 3
+__device__ __forceinline__ void swap_bit5(cf& x, cf& y) {
+    const glv_u2 r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+    const glv_u2 r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+    x = cf{__uint_as_float(r0[0]), __uint_as_float(r1[0])};
+    y = cf{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+}
+__device__ __forceinline__ void swap_bit4(cf& x, cf& y) {
+    const glv_u2 r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.x), __float_as_uint(y.x), false, false);
+    const glv_u2 r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x.y), __float_as_uint(y.y), false, false);
+    x = cf{__uint_as_float(r0[0]), __uint_as_float(r1[0])};
+    y = cf{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+}
+// row_ror:8 = lane ^ 8 inside a row of 16; banks 2,3 are the lanes with bit 3 set
+__device__ __forceinline__ float take_bit3_set(float keep, float from) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(from), 0x128, 0xF, 0xC, false));
+}
+__device__ __forceinline__ float take_bit3_clear(float keep, float from) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(from), 0x128, 0xF, 0x3, false));
+}
+__device__ __forceinline__ void swap_bit3(cf& x, cf& y) {
+    const cf xn = cf{take_bit3_set(x.x, y.x), take_bit3_set(x.y, y.y)};
+    const cf yn = cf{take_bit3_clear(y.x, x.x), take_bit3_clear(y.y, x.y)};
+    x = xn;
+    y = yn;
+}
+__device__ __forceinline__ void transpose_hi(cf (&u)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) swap_bit5(u[q], u[q + 4]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (!(q & 2)) swap_bit4(u[q], u[q + 2]);
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) swap_bit3(u[q], u[q + 1]);
+}
+#else
+#define GLV_XCHG_REGS_DEVICE 0
+#endif
+
 template <int A>
 struct WaveFft {
     using G = Geo<A>;
@@ -275,8 +325,14 @@ struct WaveFft {
             }
 #pragma unroll
             for (int k0 = 1; k0 < 8; ++k0) u[k0] = cmul(u[k0], tw[k0]);
+#if GLV_XCHG_REGS_DEVICE
+            transpose_hi(u);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) v[n1 + 8 * a] = u[n1];
+#else
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) w[a * G::X1 + 72 * k0 + lane] = u[k0];
+#endif
         }
     }
     static GLV_HD void fwd_b(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
@@ -284,8 +340,13 @@ struct WaveFft {
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
+#if GLV_XCHG_REGS_DEVICE
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) u[n1] = v[n1 + 8 * a];
+#else
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) u[n1] = r[a * G::X1 + 72 * hi + 8 * n1 + lo];
+#endif
             Dft<8, false>::run(u);
             cf tw[8];
             if (twr) {
@@ -463,19 +524,36 @@ struct WaveFft {
             for (int n1 = 0; n1 < 8; ++n1) v[n1 + 8 * a] = u[n1];
         }
     }
-    static GLV_HD void inv_b_store(const cf (&v)[E], cf* w, int lane) {
+    static GLV_HD void inv_b_store(cf (&v)[E], cf* w, int lane) {
+#if GLV_XCHG_REGS_DEVICE
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            cf u[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) u[n1] = v[n1 + 8 * a];
+            transpose_hi(u);
+#pragma unroll
+            for (int k0 = 0; k0 < 8; ++k0) v[k0 + 8 * a] = u[k0];
+        }
+#else
         const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
         for (int a = 0; a < A; ++a)
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) w[a * G::X1 + 72 * hi + 8 * n1 + lo] = v[n1 + 8 * a];
+#endif
     }
     static GLV_HD void inv_a(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
+#if GLV_XCHG_REGS_DEVICE
+#pragma unroll
+            for (int k0 = 0; k0 < 8; ++k0) u[k0] = v[k0 + 8 * a];
+#else
 #pragma unroll
             for (int k0 = 0; k0 < 8; ++k0) u[k0] = r[a * G::X1 + 72 * k0 + lane];
+#endif
             cf tw[8];
             if (twr) {
 #pragma unroll
