@@ -337,6 +337,7 @@ struct WaveFft {
     }
     static GLV_HD void fwd_b(cf (&v)[E], const Tables& t, const cf* r, int lane, const cf* twr = nullptr) {
         const int hi = lane >> 3, lo = lane & 7;
+        (void)hi;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             cf u[8];
