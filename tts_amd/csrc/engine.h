@@ -339,13 +339,18 @@ struct Engine {
     }
     // completes a fetched block into rows row0 .. row0+HB-1 of a time-side register array
     GLV_HD void finish_block(const IterArgs& a, const BlockFetch& f, cf (&dst)[E], int row0) const {
+        finish_block_w(a, f, f.w, dst, row0);
+    }
+    // the same with the window-sum-square row taken from another fetch of the same block index
+    GLV_HD void finish_block_w(const IterArgs& a, const BlockFetch& f, const cf (&w)[HV], cf (&dst)[E],
+                               int row0) const {
 #pragma unroll
         for (int s2 = 0; s2 < A; ++s2)
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
                 const int k = i + HB * s2;
                 const cf val = f.main[k] + f.tail[k];
-                const float wx = a.raw_in ? 1.0f : f.w[k].x, wy = a.raw_in ? 1.0f : f.w[k].y;
+                const float wx = a.raw_in ? 1.0f : w[k].x, wy = a.raw_in ? 1.0f : w[k].y;
                 dst[row0 + i + 8 * s2] = cf{val.x * wx, val.y * wy};
             }
     }
@@ -374,6 +379,28 @@ struct Engine {
     GLV_HD void prefetch_block_prev(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
         fetch_block_from(a, a.y_prev, a.y_prev_tail, tt + R - 1, blkp_n);
+    }
+    // both signals' newest block of frame t: one set of conditions, one window-sum-square row
+    GLV_HD void prefetch_block_pair(const IterArgs& a, int t) {
+        const int tt = t < run.t_end ? t : run.t_end - 1;
+        const int j = tt + R - 1;
+        const bool valid = block_valid(j);
+        const bool has_main = valid && (a.raw_in || j < run.n_frames);
+        const bool has_tail = valid && block_has_tail(a, j);
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
+        const float* pm = has_main ? a.y_in + base : a.zeros;
+        const float* pmp = has_main ? a.y_prev + base : a.zeros;
+        const float* pt = has_tail ? a.y_in_tail + base : a.zeros;
+        const float* ptp = has_tail ? a.y_prev_tail + base : a.zeros;
+        const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            load_row(pm, i, blk_n.main);
+            load_row(pt, i, blk_n.tail);
+            load_row(pw, i, blk_n.w);
+            load_row(pmp, i, blkp_n.main);
+            load_row(ptp, i, blkp_n.tail);
+        }
     }
     // ... and its previous spectrum and target magnitudes
     GLV_HD void prefetch_spec(const IterArgs& a, int t) {
@@ -469,9 +496,8 @@ struct Engine {
     template <bool SC>
     GLV_HD void lin_advance(const IterArgs& a, int t) {
         finish_block(a, blk_n, raw, (R - 1) * HB);
-        finish_block(a, blkp_n, v, (R - 1) * HB);
-        prefetch_block(a, t + 1);
-        prefetch_block_prev(a, t + 1);
+        finish_block_w(a, blkp_n, blk_n.w, v, (R - 1) * HB);
+        prefetch_block_pair(a, t + 1);
         combine_rows<SC, (R - 1) * HB, R * HB>(a.has_prev ? a.cmom : 0.0f);
     }
     // window one of the two arrays and start its forward transform
