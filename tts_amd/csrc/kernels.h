@@ -30,8 +30,8 @@ constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 
 // Wave priority inside the frame loop.  A SIMD issues from its oldest wave first, so without
 // help the waves of a SIMD finish one after the other and the last runs alone.  1: a wave's
-// priority falls after each third of its run and again for its last frame, which lets the
-// waves behind catch up and all of them end together.  0: priorities untouched.
+// priority falls at the middle of its run, an eighth before its end and for its last frame,
+// which lets the waves behind catch up and all of them end together.  0: priorities untouched.
 #ifndef GLV_PRIO
 #define GLV_PRIO 1
 #endif
@@ -160,7 +160,7 @@ gl_engine_kernel(IterArgs a) {
     GLV_STAMP(2)
 #if GLV_PRIO == 1
     const int prio_n = e.run.t_end - e.run.t_begin;
-    const int prio_q1 = e.run.t_begin + (prio_n + 2) / 3, prio_q2 = e.run.t_begin + (2 * prio_n + 2) / 3,
+    const int prio_q1 = e.run.t_begin + (prio_n + 1) / 2, prio_q2 = e.run.t_end - 1 - (prio_n + 7) / 8,
               prio_q3 = e.run.t_end - 1;
     __builtin_amdgcn_s_setprio(3);
 #endif
