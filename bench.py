@@ -235,7 +235,11 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "alg_bytes_per_launch": alg_bytes_iter,
-                         "kernel_ms_per_launch": round(kernel_ms, 5), "traffic": traffic},
+                         "kernel_ms_per_launch": round(kernel_ms, 5), "traffic": traffic,
+                         # measured HBM bytes per launch over the same time: the fused kernel moves
+                         # about a third of the algorithmic bytes, hence frac > 1 above
+                         "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                          if traffic else None)},
         }
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(mel_host, MEAN, STD, min(args.cpu_utts, args.batch))
