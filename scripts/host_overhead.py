@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Host time to enqueue one bench-shaped step against the time the GPU needs for it, with and
+without the hipGraph and the timing events: shows whether the host keeps ahead of the device.
+  python scripts/host_overhead.py        (on a GPU box)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
