@@ -615,3 +615,37 @@ def test_momentum_in_time_domain_and_in_frequency_domain(voc, O, n_fft, hop, win
             assert np.all(y[b, n:] == 0)
             assert np.max(np.abs(sc[b] - sc_ref) / sc_ref) < 1e-4, linear
     plan.close()
+
+
+@pytest.mark.parametrize("n_fft,hop,batch,frames", [(1024, 256, 48, 160), (2048, 256, 24, 160)])
+def test_device_filling_batch_with_automatic_runs(voc, O, n_fft, hop, batch, frames):
+    """A batch with more frames than the device has wave slots, library defaults throughout
+    (automatic run table, several frames per wave, momentum in the time domain, graph replay):
+    sampled utterances match the oracle, and the batch result does not depend on the batch."""
+    f = n_fft // 2 + 1
+    rng = np.random.default_rng(17)
+    lens = [int(x) for x in rng.integers(frames // 2, frames + 1, batch)]
+    lens[0], lens[-1] = frames, frames // 2
+    s = np.zeros((batch, frames, f), np.float32)
+    p = np.zeros((batch, frames, f, 2), np.float32)
+    for b, t in enumerate(lens):
+        s[b, :t] = rng.standard_normal((t, f)) ** 2
+        ang = 2 * np.pi * rng.random((t, f))
+        p[b, :t, :, 0], p[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, batch)
+    yb = plan.griffinlim(dev(s), lens, phase0=dev(p), n_iter=6).cpu().numpy()
+    assert np.all(np.isfinite(yb))
+    for b in (0, batch // 2, batch - 1):
+        t = lens[b]
+        n = hop * (t - 1)
+        assert np.all(yb[b, n:] == 0)
+        ref = O.griffinlim(np.ascontiguousarray(s[b, :t].T), n_iter=6, hop_length=hop, win_length=n_fft,
+                           init_phase=from_btf2(p[b, :t]))
+        assert rel_l2(yb[b, :n], ref) < 1e-4
+    # the same utterances in another order and company: only run boundaries move
+    order = list(range(batch))[::-1]
+    yr = plan.griffinlim(dev(s[order]), [lens[i] for i in order], phase0=dev(p[order]), n_iter=6).cpu().numpy()
+    for b in (0, batch // 2, batch - 1):
+        n = hop * (lens[b] - 1)
+        assert rel_l2(yr[batch - 1 - b, :n], yb[b, :n]) < 1e-5
+    plan.close()
