@@ -56,7 +56,7 @@ __device__ __forceinline__ void wave_sync() {
 // measurement build: every wave of the iteration kernel leaves four time stamps (100 MHz clock)
 __device__ unsigned long long glv_wave_times[20 * 16384];
 #define GLV_STAMP(k)                                                                          \
-    if (MODE == MODE_ITER_LIN && (threadIdx.x & 63) == 0) {                                   \
+    if ((MODE == MODE_ITER_LIN || MODE == MODE_ITER1) && (threadIdx.x & 63) == 0) {           \
         const int w_ = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);                      \
         if (w_ < 16384 && (k) < 20) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
     }
@@ -116,6 +116,7 @@ gl_engine_kernel(IterArgs a) {
         const int t = e.run.t_begin;
         if (MODE == MODE_ITER1) {
             e.template ph0_single<true>(a, t, xb);
+            GLV_STAMP(4)
             wave_sync();
             e.ph1_read(xb);
             wave_sync();
@@ -126,6 +127,7 @@ gl_engine_kernel(IterArgs a) {
             e.ph2_write(xb);
             wave_sync();
             e.template ph3_update<SC, 0, false>(a, t, xb);
+            GLV_STAMP(5)
         } else {
             e.ph3_load(a, t);
         }
@@ -138,7 +140,9 @@ gl_engine_kernel(IterArgs a) {
         wave_sync();
         e.ph5_write(xb);
         wave_sync();
+        GLV_STAMP(6)
         e.ph6_single(a, t, xb);
+        GLV_STAMP(3)
     }
     constexpr bool kLin = MODE == MODE_ITER_LIN;
     if (!kSingle && !kLin && MODE != MODE_ISTFT) {
