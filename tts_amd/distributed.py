@@ -107,16 +107,35 @@ def exchange_halos(to_prev, to_next, from_prev, from_next, *, group=None):
     first rank has no previous, the last no next neighbour).  Tensors are the
     (n_fft - hop)-sample overlap-add partial sums at the two shard boundaries."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # a transport that only moves host memory (gloo) gets host copies of device tensors
+    staged = dist.get_backend(group) != "nccl" and to_prev.is_cuda
+    send_prev, send_next = (to_prev.cpu(), to_next.cpu()) if staged else (to_prev, to_next)
+    recv_prev, recv_next = (torch.empty_like(send_prev), torch.empty_like(send_next)) if staged else (from_prev, from_next)
     ops = []
     if rank > 0:
-        ops.append(dist.P2POp(dist.isend, to_prev, rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, from_prev, rank - 1, group))
+        ops.append(dist.P2POp(dist.isend, send_prev, rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, recv_prev, rank - 1, group))
     if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, to_next, rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, from_next, rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, send_next, rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, recv_next, rank + 1, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if staged:
+        if rank > 0:
+            from_prev.copy_(recv_prev)
+        if rank < world - 1:
+            from_next.copy_(recv_next)
+
+
+def _all_reduce_max(x, group):
+    """all-reduce(MAX) of a small device tensor; through the host for transports without device support."""
+    if dist.get_backend(group) == "nccl" or not x.is_cuda:
+        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
+        return x
+    host = x.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+    return host.to(x.device)
 
 
 def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length=256, win_length=None,
@@ -162,10 +181,8 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
     y, n_begin = plan.shard_end()
     if normalize and y.numel():
         row = y.unsqueeze(0)
-        peak = plan.peak_reduce(row)
-        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)
+        peak = _all_reduce_max(plan.peak_reduce(row), group)
         plan.peak_scale(row, peak)
     elif normalize:
-        peak = torch.zeros((1,), dtype=torch.float32, device=plan.device)
-        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)
+        _all_reduce_max(torch.zeros((1,), dtype=torch.float32, device=plan.device), group)
     return y, n_begin
