@@ -651,10 +651,12 @@ def test_device_filling_batch_with_automatic_runs(voc, O, n_fft, hop, batch, fra
     plan.close()
 
 
-@pytest.mark.parametrize("n_fft,hop,frames,world", [(1024, 256, 150, 2), (2048, 256, 200, 3)])
-def test_time_sharded_two_processes(n_fft, hop, frames, world):
+@pytest.mark.parametrize("n_fft,hop,frames,world,backend", [(1024, 256, 150, 2, "gloo"), (2048, 256, 200, 3, "gloo"),
+                                                            (1024, 256, 90, 1, "nccl")])
+def test_time_sharded_two_processes(n_fft, hop, frames, world, backend):
     """`griffin_lim_time_sharded` as it is deployed: one process per shard, halos and the peak
-    exchanged through torch.distributed (here gloo, all ranks sharing the one GPU).  Rank 0
+    exchanged through torch.distributed (gloo with all ranks sharing the one GPU; RCCL with the
+    single rank a one-GPU box allows).  Rank 0
     compares the assembled waveform with the unsharded drop-in call on the same seed."""
     import os
     import subprocess
@@ -663,7 +665,26 @@ def test_time_sharded_two_processes(n_fft, hop, frames, world):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
-           os.path.join(here, "time_shard_worker.py"), str(n_fft), str(hop), str(frames)]
+           os.path.join(here, "time_shard_worker.py"), str(n_fft), str(hop), str(frames), backend]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "rel L2" in res.stdout
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 3), ("nccl", 1)])
+def test_batch_sharded_processes(backend, world):
+    """`synthesize_sharded` as it is deployed: one process per rank, utterances dealt by length,
+    waveforms gathered on rank 0 - over gloo with three processes on the one GPU, and over RCCL
+    with the one rank a one-GPU box allows (device-resident collectives).  Rank 0 compares with
+    the same utterances synthesised in one call."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29650 + world),
+           os.path.join(here, "batch_shard_worker.py"), backend]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "worst rel L2" in res.stdout

@@ -1,4 +1,4 @@
-"""Worker of test_time_sharded_two_processes: one rank of a gloo group, every rank on cuda:0.
+"""Worker of test_time_sharded_two_processes: one rank of a gloo (or one-rank RCCL) group, every rank on cuda:0.
 Rank 0 assembles the waveform and compares it with the unsharded call; its exit code is the verdict."""
 import os
 import sys
@@ -17,21 +17,27 @@ def main():
     from tts_amd.distributed import griffin_lim_time_sharded
     from tts_amd.vocoder import GriffinLimPlan
     n_fft, hop, frames, n_iter = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 6
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group(backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    gather_device = "cuda:0" if backend == "nccl" else "cpu"
     mel = synthetic_mel(77, frames)
     y, n_begin = griffin_lim_time_sharded(mel, MEAN, STD, n_fft=n_fft, hop_length=hop, n_iter=n_iter, seed=5,
                                           device=torch.device("cuda:0"))
-    piece = y.cpu()
-    meta = torch.tensor([n_begin, piece.numel()], dtype=torch.int64)
-    metas = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    piece = y.to(gather_device)
+    meta = torch.tensor([n_begin, piece.numel()], dtype=torch.int64, device=gather_device)
+    metas = [torch.zeros(2, dtype=torch.int64, device=gather_device) for _ in range(world)]
     dist.all_gather(metas, meta)
     size = max(int(m[1]) for m in metas)
-    padded = torch.zeros(size, dtype=torch.float32)
+    padded = torch.zeros(size, dtype=torch.float32, device=gather_device)
     padded[:piece.numel()] = piece
-    parts = [torch.zeros(size, dtype=torch.float32) for _ in range(world)]
+    parts = [torch.zeros(size, dtype=torch.float32, device=gather_device) for _ in range(world)]
     dist.all_gather(parts, padded)
+    parts = [p.cpu() for p in parts]
     ok = True
     if rank == 0:
         total = hop * (frames - 1)

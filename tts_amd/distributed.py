@@ -70,14 +70,15 @@ def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=
     shards = shard_by_length(lengths, world)
     max_rows = max(len(s) for s in shards)
     max_len = max((len(v) for v in local.values()), default=0)
-    dims = torch.tensor([max_len], dtype=torch.int64)
+    # RCCL moves device memory only, gloo host memory
+    on_device = dist.get_backend(group) == "nccl"
+    dims = torch.tensor([max_len], dtype=torch.int64, device="cuda" if on_device else "cpu")
     dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
     max_len = int(dims.item())
     block = torch.zeros((max_rows, max_len), dtype=torch.float32)
     for r, i in enumerate(mine):
         block[r, : len(local[i])] = torch.from_numpy(local[i])
-    backend = dist.get_backend(group)
-    if backend == "nccl":
+    if on_device:
         block = block.cuda()
     if rank == gather_dst:
         parts = [torch.empty_like(block) for _ in range(world)]
