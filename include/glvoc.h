@@ -16,7 +16,14 @@
  *   - Pointers named *_dev are device memory owned by the caller; pointers
  *     named *_host are host memory read before the call returns.
  *   - All work is enqueued on `stream` (a hipStream_t, NULL = default stream)
- *     and is asynchronous; only glv_plan_create/destroy synchronise.
+ *     and is asynchronous.  glv_plan_create / glv_plan_destroy synchronise the device, the
+ *     glv_plan_set_*_basis uploads are blocking copies, glv_plan_last_loop_ms waits for its
+ *     event.  A compute call waits on the host only in two cases: (a) it needs more of the
+ *     usage-dependent workspace than glv_plan_create / glv_plan_reserve set aside (it then
+ *     drains the stream, reallocates and drops its captured graphs), (b) the pinned staging
+ *     set it is about to rewrite still feeds the upload of the third-last call with new
+ *     lengths.  The first call with a new (lengths, n_iter, momentum) shape also captures a
+ *     hipGraph of the iteration loop; the 8 most recently used shapes stay instantiated.
  *   - A plan is bound to one device and must be used from one stream at a time.
  *   - Layouts are frame-major: mel (B, T, n_mels), spectra (B, T, F) with
  *     F = n_fft/2+1 contiguous per frame, waveforms (B, y_stride).  `T` is the
@@ -61,6 +68,29 @@ void glv_plan_destroy(glv_plan* plan);
 
 /* Bytes of device memory the plan holds. */
 int64_t glv_plan_workspace_bytes(const glv_plan* plan);
+
+/*
+ * Sets aside, ahead of time, the workspace whose size depends on how the plan is used rather
+ * than on its capacity, for calls of up to (batch, frames_stride, n_iter): the per-run partial
+ * sums of the convergence curve (sc_curve_dev != NULL) and, with single_frame != 0, the
+ * partial-sum buffers of the one-frame-per-wave iteration when that mode is FORCED (option
+ * "single_frame" = 1) on a batch larger than the automatic choice would take.
+ * glv_plan_create already reserves what the automatic mode choice and a 64-iteration curve
+ * over the automatic run table need, so most callers never call this.  No counterpart in the
+ * reference (numpy allocates per call).
+ */
+int glv_plan_reserve(glv_plan* plan, int batch, int frames_stride, int n_iter, int single_frame,
+                     void* stream);
+
+/*
+ * Identity of every utterance of the following calls, for the initial phase drawn on the device
+ * (phase0_dev == NULL): utterance b draws the stream (seed, ids_host[b]) indexed by (frame, bin),
+ * so its waveform does not depend on the batch it is in, on its row, or on frames_stride.
+ * ids_host == NULL (the state after glv_plan_create) identifies an utterance by its row.
+ * Stands in for the reference drawing a fresh default_rng per call of
+ * librosa.griffinlim (vocoder/mel_audio.py:126): one independent stream per utterance.
+ */
+int glv_plan_set_utterance_ids(glv_plan* plan, const int64_t* ids_host, int batch, void* stream);
 
 /*
  * Uploads the (F, n_mels) row-major float32 pseudo-inverse of the mel basis,

@@ -13,6 +13,8 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 EMU_SRC = os.path.join(ROOT, "tests", "csrc", "emu.cpp")
 EMU_LIB = os.path.join(ROOT, "tests", "csrc", "libglvemu.so")
+EMU64_SRC = os.path.join(ROOT, "tests", "csrc", "emu64.cpp")
+EMU64_LIB = os.path.join(ROOT, "tests", "csrc", "libglvemu64.so")
 
 
 def pytest_configure(config):
@@ -47,10 +49,27 @@ def build_emulation():
     return EMU_LIB
 
 
+def build_emulation64():
+    """The same emulation with every float compiled as double (tests/csrc/emu64.cpp): shows that
+    the engine's iteration is librosa's algorithm exactly, rounding aside."""
+    srcs = [EMU64_SRC, EMU_SRC] + [os.path.join(ROOT, "tts_amd", "csrc", h)
+                                   for h in ("wave_fft.h", "engine.h", "elementwise.h", "host_tables.h")]
+    if os.path.exists(EMU64_LIB) and all(os.path.getmtime(EMU64_LIB) >= os.path.getmtime(s) for s in srcs):
+        return EMU64_LIB
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-o", EMU64_LIB, EMU64_SRC])
+    return EMU64_LIB
+
+
 @pytest.fixture(scope="session")
 def emu():
     lib = ctypes.CDLL(build_emulation())
     return lib
+
+
+@pytest.fixture(scope="session")
+def emu64():
+    return ctypes.CDLL(build_emulation64())
 
 
 @pytest.fixture(scope="session")

@@ -20,15 +20,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_batch(mels, mean, std, hop_length=256, n_fft=1024, **kw):
-    """compute_fn with the signature of griffin_lim_batch; phase seeded by the mel itself
-    so the result does not depend on which rank gets the utterance."""
+def _oracle_batch(mels, mean, std, hop_length=256, n_fft=1024, utt_ids=None, seed=0, **kw):
+    """compute_fn with the signature of griffin_lim_batch; the phase stream is keyed by the
+    utterance's identity, so the result does not depend on which rank gets the utterance."""
     from oracle import griffinlim_oracle as O
     rows, n = [], []
-    for m in mels:
-        seed = int(np.abs(m).sum() * 1000) % (2**31)
+    for m, uid in zip(mels, utt_ids):
+        rs = 1000 * seed + uid
         y = O.mel_to_audio_griffin_lim(m, mean, std, n_fft=n_fft, win_length=n_fft, hop_length=hop_length,
-                                       n_iter=2, random_state=seed)
+                                       n_iter=2, random_state=rs)
         rows.append(y)
         n.append(len(y))
     out = np.zeros((len(rows), max(n)), np.float32)

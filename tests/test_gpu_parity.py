@@ -5,11 +5,10 @@ an identical initial phase.
 Tolerances: linear spectrogram after mel inversion within
 1e-4 relative L2; waveform after k iterations within 1e-3 relative L2 in fp32;
 per-iteration spectral-convergence curve within 1 %.  Fast Griffin-Lim with
-momentum 0.99 amplifies fp32 rounding differences exponentially in k (the
-oracle's own mixed-precision and pure-fp32 variants differ by 1.3e-3 at k=60 for
-n_fft=1024), so the waveform bound is asserted for k <= 16 everywhere and for
-k = 60 where the amplification allows (n_fft=2048); the curve bound is asserted
-at every k up to 60.
+momentum 0.99 amplifies fp32 rounding differences in k; the measured drift at
+k = 16 / 32 / 60 on the reference's own mel is printed by
+test_fixture_60_iterations (run pytest with -s, or read the captured output) and
+asserted below 1e-3 at every one of them, for both forms of the momentum term.
 """
 import numpy as np
 import pytest
@@ -105,23 +104,72 @@ def test_griffinlim_waveform_and_curve(voc, O, lj001, n_fft, hop, frames, fpr):
     plan.close()
 
 
+@pytest.mark.parametrize("form", ["time-domain momentum", "spectral momentum", "one frame per wave"])
 @pytest.mark.parametrize("n_fft,frames", [(1024, 430), (2048, 865)])
-def test_fixture_60_iterations(voc, O, lj001, n_fft, frames):
-    """The reference's own mel at the reference's iteration count."""
+def test_fixture_60_iterations(voc, O, lj001, n_fft, frames, form, capsys):
+    """The reference's own mel at the reference's iteration count (vocoder/mel_audio.py:126),
+    at the benchmark shape (n_fft 1024, 430 frames) and the reference's defaults (2048, 865):
+    waveform within 1e-3 relative L2 after 16, 32 and 60 iterations, curve within 1 %, for the
+    three forms of the iteration kernel: runs of frames per wave with the momentum term formed
+    in the time domain (the default for device-filling batches, the benchmark's kernel), the
+    same with the term formed in the frequency domain as librosa writes it, and one frame per
+    wave (what a single utterance gets by default)."""
     mel, mean, std = lj001
     s = O.mel_invert(mel[:frames], mean, std, n_fft=n_fft)
     ph = phasors(0, s.shape[0], frames)
-    y_ref, sc_ref = O.griffinlim(s, n_iter=60, hop_length=256, win_length=n_fft, init_phase=ph,
-                                 return_sc=True)
+    ks = [16, 32, 60]
+    y_ref, sc_ref, snaps = O.griffinlim(s, n_iter=60, hop_length=256, win_length=n_fft, init_phase=ph,
+                                        return_sc=True, snapshots=ks)
     plan = voc.GriffinLimPlan(n_fft, 256, n_fft, 80, frames, 1)
-    y, sc = plan.griffinlim(dev(to_btf(s)), phase0=dev(to_btf2(ph)), n_iter=60, return_sc=True)
-    y, sc = y.cpu().numpy()[0], sc.cpu().numpy()[0]
-    assert y.shape == (256 * (frames - 1),)
-    assert np.max(np.abs(sc - sc_ref) / sc_ref) < 1e-2
-    drift = rel_l2(y, y_ref)
-    # fp32 rounding amplified over 60 momentum iterations: the oracle's two precisions
-    # differ by 1.3e-3 (n_fft=1024) / 3.8e-5 (n_fft=2048) on this input
-    assert drift < (1e-2 if n_fft == 1024 else 1e-3), drift
+    plan.set_option("single_frame", 1 if form == "one frame per wave" else 0)
+    plan.set_option("linear", 0 if form == "spectral momentum" else 1)
+    sd, pd = dev(to_btf(s)), dev(to_btf2(ph))
+    drifts = {}
+    for k in ks:
+        y, sc = plan.griffinlim(sd, phase0=pd, n_iter=k, return_sc=True)
+        y, sc = y.cpu().numpy()[0], sc.cpu().numpy()[0]
+        assert y.shape == (256 * (frames - 1),)
+        assert np.max(np.abs(sc - sc_ref[:k]) / sc_ref[:k]) < 1e-2
+        drifts[k] = rel_l2(y, snaps[k])
+    with capsys.disabled():
+        print(f"\n[drift] n_fft {n_fft}, {frames} frames, {form}: "
+              + ", ".join(f"k={k}: {d:.2e}" for k, d in drifts.items())
+              + f"; curve max rel err {np.max(np.abs(sc - sc_ref) / sc_ref):.1e}")
+    for k, d in drifts.items():
+        assert d < 1e-3, (k, d)
+    plan.close()
+
+
+@pytest.mark.parametrize("name", ["stages_n1024_t16", "stages_n2048_t12"])
+def test_golden_stage_fixtures(voc, name):
+    """The committed per-stage vectors (tests/golden/stages_*.npz: the oracle's tensors for a slice
+    of the reference's mel and a fixed phase) through every C-ABI stage: mel inversion, iSTFT of
+    the initial angles, STFT of that, the waveform after 1, 2, 4, 8 iterations, the curve, and
+    the peak-normalised audio of the one-call entry point."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_fft, hop = int(g["n_fft"]), int(g["hop"])
+    mel, mean, std = g["mel_db"], float(g["mean"]), float(g["std"])
+    s, ph = g["linear_spec"], g["phase0"]
+    frames = s.shape[1]
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, 1)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    got_s = plan.mel_invert(dev(mel[None]), mean, std)
+    assert rel_l2(got_s.cpu().numpy()[0], s.T) < 1e-4
+    pd = dev(to_btf2(ph))
+    for single in (0, 1):
+        plan.set_option("single_frame", single)
+        for k in (0, 1, 2, 4, 8):
+            y, sc = plan.griffinlim(got_s, phase0=pd, n_iter=max(k, 1), return_sc=True) if k else \
+                (plan.griffinlim(got_s, phase0=pd, n_iter=0), None)
+            assert rel_l2(y.cpu().numpy()[0], g[f"y_k{k}"]) < 1e-4, (single, k)
+            if k:
+                assert np.max(np.abs(sc.cpu().numpy()[0] - g["sc"][:k]) / g["sc"][:k]) < 1e-4
+    d1 = plan.stft(dev(g["y_k0"][None])).cpu().numpy()[0]
+    assert rel_l2(from_btf2(d1), g["rebuilt_k1"]) < 2e-6
+    audio = plan.mel_to_audio(dev(mel[None]), mean, std, phase0=pd, n_iter=8).cpu().numpy()[0]
+    assert rel_l2(audio, g["audio"]) < 1e-4
     plan.close()
 
 
@@ -197,17 +245,26 @@ def test_drop_in_on_reference_fixture(voc, O, lj001):
     length law, peak normalisation, and the quality window its own outputs sit in
     (best-gain spectral convergence 0.1709 / 0.1738 for the two shipped wavs)."""
     mel, mean, std = lj001
-    audio = voc.mel_to_audio_griffin_lim(mel, mean, std)
+    a = np.abs(O.mel_invert(mel, mean, std)).astype(np.float64)
+
+    def best_gain_sc(audio):
+        d = np.abs(O.stft(audio, n_fft=2048, hop_length=256, win_length=2048)).astype(np.float64)
+        g = (d * a).sum() / (d * d).sum()
+        return np.linalg.norm(g * d - a) / np.linalg.norm(a)
+
+    # the oracle's known-answer window, with the oracle test's phase (default_rng(4))
+    audio = voc.mel_to_audio_griffin_lim(mel, mean, std, init_phase=4)
     assert isinstance(audio, np.ndarray) and audio.dtype == np.float32
     assert audio.shape == (221184,)
     peak = float(np.max(np.abs(audio)))
     assert 0.99998 < peak <= 1.0
-    a = np.abs(O.mel_invert(mel, mean, std)).astype(np.float64)
-    d = np.abs(O.stft(audio, n_fft=2048, hop_length=256, win_length=2048)).astype(np.float64)
-    g = (d * a).sum() / (d * d).sum()
-    sc = np.linalg.norm(g * d - a) / np.linalg.norm(a)
-    # the unseeded phase moves the end point a little: five oracle seeds give 0.170-0.173,
-    # an occasional one 0.187
+    sc = best_gain_sc(audio)
+    assert 0.165 < sc < 0.180, sc
+    # the reference's own call: unseeded phase, drawn on the device.  The end point moves a
+    # little with the phase (oracle seeds: 0.170-0.173, an occasional 0.187)
+    audio = voc.mel_to_audio_griffin_lim(mel, mean, std)
+    assert audio.shape == (221184,) and 0.99998 < float(np.max(np.abs(audio))) <= 1.0
+    sc = best_gain_sc(audio)
     assert 0.16 < sc < 0.20, sc
     # seeded phase == oracle with the same generator
     y1 = voc.mel_to_audio_griffin_lim(mel[:100], mean, std, n_iter=8, init_phase=3)
@@ -215,24 +272,98 @@ def test_drop_in_on_reference_fixture(voc, O, lj001):
     assert rel_l2(y1, y2) < 1e-3
 
 
-def test_full_size_batch_properties(voc):
+def test_full_size_batch_properties(voc, O):
     """The benchmark batch shape (64 utterances x 430 frames, n_fft=1024, 60 iterations):
-    size-independent properties instead of an oracle run."""
+    size-independent properties, sampled rows against the oracle on the device-drawn phase, and
+    row independence - an utterance synthesised alone, with its identity, gives the same bits."""
     b, frames, n_fft, hop = 64, 430, 1024, 256
     mels = np.stack([synthetic_mel(1234 + i, frames) for i in range(b)])
-    y, n, sc = voc.griffin_lim_batch(mels, MEAN, STD, n_fft=n_fft, win_length=n_fft, hop_length=hop,
-                                     n_iter=60, seed=99, return_sc=True)
+    kw = dict(n_fft=n_fft, win_length=n_fft, hop_length=hop, n_iter=60, seed=99, frames_per_run=9)
+    y, n, sc = voc.griffin_lim_batch(mels, MEAN, STD, return_sc=True, **kw)
     y, sc = y.cpu().numpy(), sc.cpu().numpy()
     assert y.shape == (b, hop * (frames - 1)) and n == [hop * (frames - 1)] * b
     assert np.all(np.isfinite(y)) and np.all(np.isfinite(sc))
     assert np.allclose(np.max(np.abs(y), axis=1), 1.0, atol=1e-3)
     # Griffin-Lim converges: the curve ends far below where it starts, for every row
     assert np.all(sc[:, -1] < 0.6 * sc[:, 0])
-    # rows are independent: row 5 alone gives the same samples
-    y5, _ = voc.griffin_lim_batch(mels[5:6], MEAN, STD, n_fft=n_fft, win_length=n_fft, hop_length=hop,
-                                  n_iter=60, seed=99)
-    # (device-drawn phase is indexed by position in the batch, so compare via explicit phase)
-    assert y5.shape == (1, hop * (frames - 1))
+    # rows are independent: rows 5 and 63 alone, keyed by their identity, give the same samples
+    for row in (5, 63):
+        y1, _ = voc.griffin_lim_batch(mels[row:row + 1], MEAN, STD, utt_ids=[row], **kw)
+        assert np.array_equal(y1.cpu().numpy()[0], y[row])
+    # ... and in other company, at another row, with another row stride
+    sub = [mels[63], np.concatenate([mels[5], mels[5][:20]]), mels[5]]
+    y3, _ = voc.griffin_lim_batch(sub, MEAN, STD, utt_ids=[63, 1000, 5], **kw)
+    y3 = y3.cpu().numpy()
+    assert np.array_equal(y3[0, :hop * (frames - 1)], y[63]) and np.array_equal(y3[2, :hop * (frames - 1)], y[5])
+    # the library's own run table (fitted to the whole batch) moves run boundaries only
+    kw_auto = dict(kw, frames_per_run=None)
+    ya, _ = voc.griffin_lim_batch(mels, MEAN, STD, **kw_auto)
+    assert rel_l2(ya.cpu().numpy()[5], y[5]) < 1e-3
+
+
+def test_configs2_batch_of_4096(voc, O):
+    """BASELINE configs[2] on one GPU: 4096 synthetic utterances x 430 frames, 60 iterations, one
+    call.  Size-independent properties over the whole batch, and sampled rows against the oracle:
+    every sampled utterance is re-synthesised alone with an explicit phase by the library and
+    by the oracle (1e-3), and alone with its identity on the device-drawn phase, which must give
+    the bits it got inside the batch of 4096."""
+    b, frames, n_fft, hop = 4096, 430, 1024, 256
+    base = [synthetic_mel(5000 + i, frames) for i in range(32)]
+    # 4096 distinct utterances from 32 spectral envelopes: time-reversed / shifted copies
+    mels = np.empty((b, frames, 80), np.float32)
+    for i in range(b):
+        m = base[i % 32]
+        mels[i] = np.roll(m[::-1] if (i // 32) % 2 else m, 3 * (i // 64), axis=0)
+    kw = dict(n_fft=n_fft, win_length=n_fft, hop_length=hop, n_iter=60, seed=2024, frames_per_run=36)
+    y, n, sc = voc.griffin_lim_batch(mels, MEAN, STD, return_sc=True, **kw)
+    assert y.shape == (b, hop * (frames - 1)) and n == [hop * (frames - 1)] * b
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(sc).all())
+    peaks = y.abs().amax(dim=1)
+    assert bool(((peaks > 0.999) & (peaks <= 1.0)).all())
+    assert bool((sc[:, -1] < 0.6 * sc[:, 0]).all())
+    # distinct utterances give distinct waveforms, equal mels with different identities too
+    assert not torch.equal(y[0], y[64 * 2])
+    rows = [0, 1777, 4095]
+    picked = y[rows].cpu().numpy()
+    sc_picked = sc[rows].cpu().numpy()
+    del y, sc
+    for i, row in enumerate(rows):
+        y1, _, sc1 = voc.griffin_lim_batch(mels[row:row + 1], MEAN, STD, utt_ids=[row], return_sc=True, **kw)
+        assert np.array_equal(y1.cpu().numpy()[0], picked[i])
+        # the oracle on the same mel: the curve is phase-independent to a few percent at the end
+        # and the waveform check needs the same phase, so both get an explicit one
+        ph = phasors(row, n_fft // 2 + 1, frames)
+        p0 = dev(to_btf2(ph))
+        yo = O.mel_to_audio_griffin_lim(mels[row], MEAN, STD, n_fft=n_fft, win_length=n_fft, hop_length=hop,
+                                        n_iter=60, init_phase=ph)
+        kw2 = {k: v for k, v in kw.items() if k != "seed"}
+        s = O.mel_invert(mels[row], MEAN, STD, n_fft=n_fft)
+        ks = [16, 32, 60]
+        _, sc_o, snaps = O.griffinlim(s, n_iter=60, hop_length=hop, win_length=n_fft, init_phase=ph,
+                                      return_sc=True, snapshots=ks)
+        # How far the reference computation itself moves when only its precision changes: these
+        # smoothed-noise mels make the momentum iteration far more sensitive to rounding than
+        # speech does (the engine compiled in double agrees with the double oracle to 1e-9,
+        # tests/test_engine_emulation.py), so beyond k = 32 "within 1e-3" is below what fp32
+        # defines and the bound becomes that sensitivity
+        _, snaps64 = O.griffinlim(s.astype(np.float64), n_iter=60, hop_length=hop, win_length=n_fft,
+                                  init_phase=ph.astype(np.complex128), snapshots=ks)
+        for k in ks:
+            yk, _ = voc.griffin_lim_batch(mels[row:row + 1], MEAN, STD, phase0=p0, normalize=False,
+                                          **dict(kw2, n_iter=k))
+            d = rel_l2(yk.cpu().numpy()[0], snaps[k])
+            floor = rel_l2(snaps[k], snaps64[k])
+            print(f"[configs2] row {row} k={k}: rel L2 vs oracle {d:.2e} (oracle fp32 vs fp64: {floor:.2e})")
+            assert d < max(1e-3, 3 * floor), (row, k, d, floor)
+            assert k > 32 or d < 1e-3, (row, k, d)
+        yg, _ = voc.griffin_lim_batch(mels[row:row + 1], MEAN, STD, phase0=p0, **kw2)
+        floor = rel_l2(snaps[60], snaps64[60])
+        assert rel_l2(yg.cpu().numpy()[0], yo) < max(1e-3, 3 * floor)
+        _, _, sc_g = voc.griffin_lim_batch(mels[row:row + 1], MEAN, STD, phase0=p0, return_sc=True, **kw2)
+        assert np.max(np.abs(sc_g.cpu().numpy()[0] - sc_o) / sc_o) < 1e-2
+        # the batch's own curve (another phase) ends within a few percent of the oracle's
+        assert abs(sc_picked[i, -1] - sc_o[-1]) < 0.1 * sc_o[-1]
+    voc._plans.clear()
 
 
 def test_error_behaviour(voc):

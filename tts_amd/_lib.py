@@ -23,6 +23,10 @@ SIGNATURES = {
                                        ctypes.c_int]),
     "glv_plan_destroy": (None, [ctypes.c_void_p]),
     "glv_plan_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
+    "glv_plan_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_void_p]),
+    "glv_plan_set_utterance_ids": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                                  ctypes.c_int, ctypes.c_void_p]),
     "glv_plan_set_inverse_basis": (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
     "glv_mel_invert": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_void_p,

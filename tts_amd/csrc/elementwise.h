@@ -14,7 +14,17 @@ struct LayoutArgs {
     const int* n_frames;      // [batch] frames of the whole utterance
     int frames_local;         // > 0: only this many frames are held here (time shard)
     int64_t frame_origin;     // global index of local frame 0 (time shard), else 0
+    const int64_t* utt_ids;   // [batch] identity of every utterance for the device-drawn phase, or
+                              // null: its position in the batch
 };
+
+// Device-drawn initial phase of (utterance b, frame t, bin k): the stream is keyed by the
+// utterance's identity and indexed by (global frame, bin), so an utterance gets the same phase
+// whatever batch it travels in, wherever it sits there and whatever the row stride is.
+GLV_HD cf drawn_phase(const LayoutArgs& L, uint64_t seed, int b, int t, int k) {
+    const uint64_t id = L.utt_ids ? (uint64_t)L.utt_ids[b] : (uint64_t)b;
+    return counter_phasor(seed ^ (id * 0x9E3779B97F4A7C15ull), (uint64_t)((t + L.frame_origin) * L.F + k));
+}
 
 // --- natural (B, T, F) arrays -> native state for the iteration -------------
 // One call per (utterance b, frame t, native position q).  angles = phase * S is
@@ -32,7 +42,7 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
     snat[native_s_index(reg, lane)] = s;
     auto phase_at = [&](int kk) -> cf {
         if (phase_nat) return phase_nat[fr * L.F + kk];
-        return counter_phasor(seed, (uint64_t)((fr + L.frame_origin) * L.F + kk));
+        return drawn_phase(L, seed, b, t, kk);
     };
     const cf p = phase_at(k);
     cf ang = cf{p.x * s * inv_n, p.y * s * inv_n};

@@ -835,7 +835,7 @@ GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return cf{__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u)};
 #else
-    const float ph = 6.28318530717958647692f * u;
+    const float ph = 6.28318530717958647692 * u;
     return cf{cosf(ph), sinf(ph)};
 #endif
 }

@@ -93,18 +93,30 @@ struct glv_plan {
     int* d_run_off = nullptr;
     int* d_run_cnt = nullptr;
     unsigned* d_peak = nullptr;
+    int64_t* d_utt_ids = nullptr;  // identities for the device-drawn phase (glv_plan_set_utterance_ids)
+    bool have_ids = false;
     float* d_sc_partial = nullptr;
     size_t sc_partial_cap = 0;
     int64_t ws_bytes = 0;
-    // host mirrors of the run bookkeeping (pinned)
-    RunDesc* h_runs = nullptr;
-    unsigned char* h_flags = nullptr;
-    int* h_ints = nullptr;  // nframes | run_off | run_cnt
+    // Host mirrors of the run bookkeeping: pinned staging sets used in rotation.  A set is
+    // rewritten only after the copies that read it have completed (its event), so a call with
+    // new lengths does not have to drain the stream.
+    struct Staging {
+        RunDesc* runs = nullptr;
+        unsigned char* flags = nullptr;
+        int* ints = nullptr;  // nframes | run_off | run_cnt
+        int64_t* ids = nullptr;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    };
+    static constexpr int kStagingSets = 3;
+    Staging stage[kStagingSets];
+    int stage_next = 0;
     size_t max_runs = 0;
     std::vector<int> cur_nframes;
     int cur_frames_stride = -1, cur_fpr = -1, n_runs = 0;
-    // graph cache for the iteration loop
-    hipGraphExec_t graph_exec = nullptr;
+    // graph cache for the iteration loop: the most recently used shapes stay instantiated, so a
+    // serving loop that alternates between a few batch shapes replays instead of re-capturing
     struct GraphKey {
         int n_runs, n_iter, with_sc, frames_stride, batch, single;
         float cmom;
@@ -113,7 +125,15 @@ struct glv_plan {
                    frames_stride == o.frames_stride && batch == o.batch && single == o.single &&
                    cmom == o.cmom;
         }
-    } graph_key{};
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraphExec_t exec;
+        uint64_t last_use;
+    };
+    static constexpr size_t kGraphCache = 8;
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
     // time-shard state (glv_shard_*): frames [t0, t1) of a T-frame utterance live here
     bool shard_active = false;
     int shard_t0 = 0, shard_t1 = 0, shard_T = 0, shard_cur = 0, shard_k = 0;
@@ -249,27 +269,51 @@ hipError_t dmalloc(glv_plan* p, T** ptr, size_t count) {
     return e;
 }
 
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// kernel arguments baked into captured graphs went stale (an option or a buffer changed)
+void drop_graphs(glv_plan* p) {
+    for (auto& g : p->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    p->graphs.clear();
+}
+
 void plan_free(glv_plan* p) {
     if (!p) return;
-    (void)hipSetDevice(p->device);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    DeviceGuard guard(p->device);
+    drop_graphs(p);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     void* dev[] = {p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
-                   p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial};
+                   p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial, p->d_utt_ids};
     for (void* q : dev)
         if (q) (void)hipFree(q);
-    if (p->h_runs) (void)hipHostFree(p->h_runs);
-    if (p->h_flags) (void)hipHostFree(p->h_flags);
-    if (p->h_ints) (void)hipHostFree(p->h_ints);
+    for (auto& sg : p->stage) {
+        if (sg.runs) (void)hipHostFree(sg.runs);
+        if (sg.flags) (void)hipHostFree(sg.flags);
+        if (sg.ints) (void)hipHostFree(sg.ints);
+        if (sg.ids) (void)hipHostFree(sg.ids);
+        if (sg.done) (void)hipEventDestroy(sg.done);
+    }
     delete p;
 }
 
 ElemArgs elem_args(const glv_plan* p, int batch, int frames_stride) {
     ElemArgs ea;
     ea.L = LayoutArgs{p->n_fft, p->hop, p->F, p->P, p->R, frames_stride,
-                      (int64_t)p->blocks * p->hop, p->d_nframes, 0, 0};
+                      (int64_t)p->blocks * p->hop, p->d_nframes, 0, 0,
+                      p->have_ids ? p->d_utt_ids : nullptr};
     ea.batch = batch;
     return ea;
 }
@@ -304,6 +348,66 @@ void set_io(const glv_plan* p, IterArgs& a, int in, int out) {
     a.y_out_tail = p->d_yt[out];
 }
 
+// Next pinned staging set of the rotation.  The host waits only if the copies enqueued the
+// last time this set was used (kStagingSets calls ago) have still not run.
+int acquire_staging(glv_plan* p, glv_plan::Staging** out) {
+    glv_plan::Staging* sg = &p->stage[p->stage_next];
+    p->stage_next = (p->stage_next + 1) % glv_plan::kStagingSets;
+    if (sg->in_flight) {
+        HIP_TRY(hipEventSynchronize(sg->done));
+        sg->in_flight = false;
+    }
+    *out = sg;
+    return GLV_OK;
+}
+hipError_t release_staging(glv_plan::Staging* sg, hipStream_t st) {
+    const hipError_t e = hipEventRecord(sg->done, st);
+    sg->in_flight = e == hipSuccess;
+    return e;
+}
+
+// Workspace that depends on how the plan is used, not only on its capacity: the partial-sum
+// buffers of the one-frame-per-wave modes and the per-run partials of the convergence curve.
+// glv_plan_create reserves what the automatic mode choice can ask for; growing later has to
+// wait for the stream (the old buffer may be in use) and invalidates the captured graphs.
+int ensure_parts(glv_plan* p, size_t need, hipStream_t st) {
+    if (need <= p->parts_cap) return GLV_OK;
+    if (p->d_parts) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(p->d_parts);
+        p->ws_bytes -= (int64_t)(p->parts_cap * sizeof(float));
+    }
+    p->d_parts = nullptr;
+    p->parts_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_parts), need * sizeof(float)));
+    p->parts_cap = need;
+    p->ws_bytes += (int64_t)(need * sizeof(float));
+    drop_graphs(p);
+    return GLV_OK;
+}
+int ensure_sc(glv_plan* p, size_t need, hipStream_t st) {
+    if (need <= p->sc_partial_cap) return GLV_OK;
+    if (p->d_sc_partial) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(p->d_sc_partial);
+        p->ws_bytes -= (int64_t)(p->sc_partial_cap * sizeof(float));
+    }
+    p->d_sc_partial = nullptr;
+    p->sc_partial_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_sc_partial), need * sizeof(float)));
+    p->sc_partial_cap = need;
+    p->ws_bytes += (int64_t)(need * sizeof(float));
+    drop_graphs(p);
+    return GLV_OK;
+}
+// runs a call of this shape can have at most, by mode
+size_t runs_bound(const glv_plan* p, int64_t frames, bool single) {
+    if (single) return (size_t)frames;
+    if (p->frames_per_run > 0) return (size_t)(frames / std::max(1, std::min(p->frames_per_run, p->R - 1)) + 1);
+    const int64_t rounds = std::max<int64_t>(1, (frames + (int64_t)p->wave_slots * 64 - 1) / ((int64_t)p->wave_slots * 64));
+    return (size_t)(p->wave_slots * rounds + p->max_batch);
+}
+
 // (Re)builds the run table for these lengths and uploads it.  Cached: a call with
 // the lengths of the previous call costs nothing.
 int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st,
@@ -321,8 +425,6 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
                       p->cur_fpr == p->frames_per_run && p->cur_single == single &&
                       memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
     if (same) return GLV_OK;
-    // the pinned staging buffers may still feed an earlier call's copies
-    HIP_TRY(hipStreamSynchronize(st));
     std::vector<RunDesc> runs;
     if (single) {
         for (int b = 0; b < batch; ++b)
@@ -334,22 +436,19 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         // slots in a whole number of rounds: a handful of runs left over for an extra,
         // nearly empty round would cost a full round of time.
         int64_t total = 0;
-        int max_t = 0;
-        for (int b = 0; b < batch; ++b) {
-            total += n_frames_host[b];
-            max_t = std::max(max_t, n_frames_host[b]);
-        }
+        for (int b = 0; b < batch; ++b) total += n_frames_host[b];
         const int64_t slots = p->wave_slots;
         const int64_t rounds = std::max<int64_t>(1, (total + slots * 64 - 1) / (slots * 64));
-        const int64_t cap = slots * rounds;
-        runs = build_runs_target(n_frames_host, batch, cap, p->R);
-        (void)max_t;
+        runs = build_runs_target(n_frames_host, batch, slots * rounds, p->R);
     }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
     std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);
-    memcpy(p->h_runs, runs.data(), runs.size() * sizeof(RunDesc));
-    memcpy(p->h_flags, flags.data(), flags.size());
-    int* nf = p->h_ints;
+    glv_plan::Staging* sg = nullptr;
+    int rc = acquire_staging(p, &sg);
+    if (rc != GLV_OK) return rc;
+    memcpy(sg->runs, runs.data(), runs.size() * sizeof(RunDesc));
+    memcpy(sg->flags, flags.data(), flags.size());
+    int* nf = sg->ints;
     int* off = nf + p->max_batch;
     int* cnt = off + p->max_batch;
     for (int b = 0; b < batch; ++b) {
@@ -361,11 +460,12 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         if (cnt[runs[r].utt] == 0) off[runs[r].utt] = (int)r;
         cnt[runs[r].utt]++;
     }
-    HIP_TRY(hipMemcpyAsync(p->d_runs, p->h_runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(p->d_flags, p->h_flags, flags.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_runs, sg->runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_flags, sg->flags, flags.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(p->d_nframes, nf, sizeof(int) * batch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(p->d_run_off, off, sizeof(int) * batch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(p->d_run_cnt, cnt, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+    HIP_TRY(release_staging(sg, st));
     p->cur_nframes.assign(n_frames_host, n_frames_host + batch);
     p->cur_frames_stride = frames_stride;
     p->cur_fpr = p->frames_per_run;
@@ -375,18 +475,6 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
 }
 
 size_t engine_grid(const glv_plan* p) { return (size_t)(p->n_runs + kWavesPerBlock - 1) / kWavesPerBlock; }
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 }  // namespace
 
@@ -484,9 +572,14 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(dmalloc(p, &p->d_run_off, (size_t)max_batch));
     PLAN_TRY(dmalloc(p, &p->d_run_cnt, (size_t)max_batch));
     PLAN_TRY(dmalloc(p, &p->d_peak, (size_t)max_batch));
-    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_runs), p->max_runs * sizeof(RunDesc)));
-    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_flags), (size_t)max_batch * p->blocks));
-    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_ints), sizeof(int) * 4 * max_batch));
+    PLAN_TRY(dmalloc(p, &p->d_utt_ids, (size_t)max_batch));
+    for (auto& sg : p->stage) {
+        PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&sg.runs), p->max_runs * sizeof(RunDesc)));
+        PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&sg.flags), (size_t)max_batch * p->blocks));
+        PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&sg.ints), sizeof(int) * 4 * max_batch));
+        PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&sg.ids), sizeof(int64_t) * max_batch));
+        PLAN_TRY(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+    }
     PLAN_TRY(hipMemcpy(p->d_tables, tab.fft.data(), tab.fft.size() * sizeof(cf), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(p->d_w2, tab.w2.data(), tab.w2.size() * sizeof(float), hipMemcpyHostToDevice));
     PLAN_TRY(hipMemcpy(p->d_iwss, tab.iwss.data(), tab.iwss.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -498,6 +591,20 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipDeviceSynchronize());
 #undef PLAN_TRY
+    {
+        // what the automatic choices can ask for: one frame per wave up to 4 x wave_slots padded
+        // blocks, and a 64-iteration convergence curve over the automatic run table
+        const int64_t pad_blocks = std::min<int64_t>((int64_t)max_batch * p->blocks, 4 * (int64_t)p->wave_slots);
+        int rc = ensure_parts(p, (size_t)2 * p->R * pad_blocks * hop, nullptr);
+        if (rc == GLV_OK)
+            rc = ensure_sc(p, (size_t)64 * 2 * std::max(runs_bound(p, (int64_t)frames, false),
+                                                        (size_t)std::min<int64_t>((int64_t)frames, 2 * (int64_t)p->wave_slots)),
+                           nullptr);
+        if (rc != GLV_OK) {
+            plan_free(p);
+            return rc;
+        }
+    }
     *out = p;
     return GLV_OK;
 }
@@ -518,10 +625,7 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->frames_per_run = value;
     } else if (!strcmp(name, "linear")) {
         p->linear = value != 0;
-        if (p->graph_exec) {
-            (void)hipGraphExecDestroy(p->graph_exec);
-            p->graph_exec = nullptr;
-        }
+        drop_graphs(p);
     } else if (!strcmp(name, "single_frame")) {
         if (value < -1 || value > 1) return fail(GLV_ERR_INVALID, "single_frame must be -1 (automatic), 0 or 1");
         p->single_frame = value;
@@ -531,26 +635,53 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->timing = value != 0;
     } else if (!strcmp(name, "alias_utts")) {
         p->alias_utts = value != 0;
-        if (p->graph_exec) {
-            (void)hipGraphExecDestroy(p->graph_exec);
-            p->graph_exec = nullptr;
-        }
+        drop_graphs(p);
     } else if (!strcmp(name, "recompute")) {
         p->recompute = value != 0;
-        if (p->graph_exec) {
-            (void)hipGraphExecDestroy(p->graph_exec);
-            p->graph_exec = nullptr;
-        }
+        drop_graphs(p);
     } else if (!strcmp(name, "traffic_only")) {
         p->traffic_only = value != 0;
-        if (p->graph_exec) {
-            (void)hipGraphExecDestroy(p->graph_exec);
-            p->graph_exec = nullptr;
-        }
+        drop_graphs(p);
     } else {
         return fail(GLV_ERR_INVALID, "unknown option '%s'", name);
     }
     return GLV_OK;
+}
+
+extern "C" int glv_plan_set_utterance_ids(glv_plan* p, const int64_t* ids_host, int batch, void* stream) {
+    if (!p) return fail(GLV_ERR_INVALID, "null plan");
+    if (!ids_host) {
+        p->have_ids = false;
+        return GLV_OK;
+    }
+    if (batch < 1 || batch > p->max_batch)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    glv_plan::Staging* sg = nullptr;
+    int rc = acquire_staging(p, &sg);
+    if (rc != GLV_OK) return rc;
+    memcpy(sg->ids, ids_host, sizeof(int64_t) * batch);
+    HIP_TRY(hipMemcpyAsync(p->d_utt_ids, sg->ids, sizeof(int64_t) * batch, hipMemcpyHostToDevice, st));
+    HIP_TRY(release_staging(sg, st));
+    p->have_ids = true;
+    return GLV_OK;
+}
+
+extern "C" int glv_plan_reserve(glv_plan* p, int batch, int frames_stride, int n_iter, int single_frame,
+                                void* stream) {
+    if (!p) return fail(GLV_ERR_INVALID, "null plan");
+    if (batch < 1 || batch > p->max_batch || frames_stride < 1 || frames_stride > p->max_frames || n_iter < 0)
+        return fail(GLV_ERR_INVALID, "shape outside the plan's capacity");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t frames = (int64_t)batch * frames_stride;
+    int rc = GLV_OK;
+    if (single_frame)
+        rc = ensure_parts(p, (size_t)2 * p->R * batch * (frames_stride + p->R) * p->hop, st);
+    if (rc == GLV_OK && n_iter > 0)
+        rc = ensure_sc(p, (size_t)n_iter * 2 * runs_bound(p, frames, single_frame != 0), st);
+    return rc;
 }
 
 extern "C" int glv_plan_last_loop_ms(glv_plan* p, float* ms_out) {
@@ -727,19 +858,10 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (single) {
         p->parts_utt_stride = (int64_t)(frames_stride + p->R) * p->hop;
         p->parts_stride = (int64_t)batch * p->parts_utt_stride;
-        const size_t need = (size_t)2 * p->R * p->parts_stride;
-        if (need > p->parts_cap) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (p->d_parts) (void)hipFree(p->d_parts);
-            p->d_parts = nullptr;
-            p->parts_cap = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_parts), need * sizeof(float)));
-            p->parts_cap = need;
-            if (p->graph_exec) {
-                (void)hipGraphExecDestroy(p->graph_exec);
-                p->graph_exec = nullptr;
-            }
-        }
+        // beyond what the plan reserved (only when the mode is forced on a large batch) this
+        // grows the buffer, which drains the stream: see glv_plan_reserve
+        rc = ensure_parts(p, (size_t)2 * p->R * p->parts_stride, st);
+        if (rc != GLV_OK) return rc;
     }
     int max_t = 0;
     for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
@@ -748,18 +870,8 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
                     (long long)y_stride, (long long)p->hop * (max_t - 1));
     const bool with_sc = sc_curve_dev != nullptr && n_iter > 0;
     if (with_sc) {
-        const size_t need = (size_t)n_iter * p->n_runs * 2;
-        if (need > p->sc_partial_cap) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (p->d_sc_partial) (void)hipFree(p->d_sc_partial);
-            p->d_sc_partial = nullptr;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_sc_partial), need * sizeof(float)));
-            p->sc_partial_cap = need;
-            if (p->graph_exec) {
-                (void)hipGraphExecDestroy(p->graph_exec);
-                p->graph_exec = nullptr;
-            }
-        }
+        rc = ensure_sc(p, (size_t)n_iter * p->n_runs * 2, st);
+        if (rc != GLV_OK) return rc;
     }
     ElemArgs ea = elem_args(p, batch, frames_stride);
     const float inv_n = 1.0f / (float)p->n_fft;
@@ -788,11 +900,19 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         if (p->use_graph) {
             const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch,
                                          single ? 1 : 0, cmom};
-            if (!p->graph_exec || !(key == p->graph_key)) {
-                if (p->graph_exec) {
-                    (void)hipGraphExecDestroy(p->graph_exec);
-                    p->graph_exec = nullptr;
+            glv_plan::GraphEntry* hit = nullptr;
+            for (auto& g : p->graphs)
+                if (g.key == key) hit = &g;
+            if (!hit) {
+                if (p->graphs.size() >= glv_plan::kGraphCache) {
+                    // evict the least recently used shape
+                    size_t lru = 0;
+                    for (size_t i = 1; i < p->graphs.size(); ++i)
+                        if (p->graphs[i].last_use < p->graphs[lru].last_use) lru = i;
+                    (void)hipGraphExecDestroy(p->graphs[lru].exec);
+                    p->graphs.erase(p->graphs.begin() + lru);
                 }
+                hipGraphExec_t exec = nullptr;
                 hipStream_t cap = nullptr;
                 HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
                 hipGraph_t graph = nullptr;
@@ -802,17 +922,17 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
                     lrc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, cap, nullptr, single);
                     e = hipStreamEndCapture(cap, &graph);
                 }
-                if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+                if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 if (graph) (void)hipGraphDestroy(graph);
                 (void)hipStreamDestroy(cap);
                 if (lrc != GLV_OK) return lrc;
-                if (e != hipSuccess) {
-                    p->graph_exec = nullptr;
+                if (e != hipSuccess)
                     return fail(GLV_ERR_HIP, "capturing the iteration loop failed: %s", hipGetErrorString(e));
-                }
-                p->graph_key = key;
+                p->graphs.push_back(glv_plan::GraphEntry{key, exec, 0});
+                hit = &p->graphs.back();
             }
-            HIP_TRY(hipGraphLaunch(p->graph_exec, st));
+            hit->last_use = ++p->graph_clock;
+            HIP_TRY(hipGraphLaunch(hit->exec, st));
         } else {
             rc = enqueue_loop(p, frames_stride, n_iter, cmom, with_sc, st, nullptr, single);
             if (rc != GLV_OK) return rc;
@@ -932,7 +1052,6 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
         return fail(GLV_ERR_INVALID, "a shard needs at least %d frames", 2 * (p->R - 1));
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(st));  // pinned staging buffers are rewritten below
     int fpr = p->frames_per_run;
     if (fpr <= 0) fpr = std::max(p->R - 1, (frames_local + p->wave_slots - 1) / p->wave_slots);
     std::vector<RunDesc> runs = build_runs(&frames_local, 1, fpr, p->R);
@@ -950,12 +1069,16 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
         for (int q = 0; q < p->R - 1; ++q) mark(r.t_end + q);
     if (t0 > 0)
         for (int q = 0; q < p->R - 1; ++q) mark(t0 + q);  // tails of the previous shard's last run
-    memcpy(p->h_runs, runs.data(), runs.size() * sizeof(RunDesc));
-    memcpy(p->h_flags, flags.data(), flags.size());
-    p->h_ints[0] = T;
-    HIP_TRY(hipMemcpyAsync(p->d_runs, p->h_runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(p->d_flags, p->h_flags, flags.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(p->d_nframes, p->h_ints, sizeof(int), hipMemcpyHostToDevice, st));
+    glv_plan::Staging* sg = nullptr;
+    int rc = acquire_staging(p, &sg);
+    if (rc != GLV_OK) return rc;
+    memcpy(sg->runs, runs.data(), runs.size() * sizeof(RunDesc));
+    memcpy(sg->flags, flags.data(), flags.size());
+    sg->ints[0] = T;
+    HIP_TRY(hipMemcpyAsync(p->d_runs, sg->runs, runs.size() * sizeof(RunDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_flags, sg->flags, flags.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_nframes, sg->ints, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(release_staging(sg, st));
     p->cur_nframes.clear();  // the batch path must rebuild its own tables afterwards
     p->n_runs = (int)runs.size();
     p->shard_t0 = t0;
@@ -972,6 +1095,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     ElemArgs ea = elem_args(p, 1, p->max_frames);
     ea.L.frames_local = frames_local;
     ea.L.frame_origin = t0;
+    ea.L.utt_ids = nullptr;  // one utterance: its phase stream is keyed by the seed alone
     p->launch_init(ea, S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, 1.0f / (float)p->n_fft, p->d_S,
                    p->d_spec, st);
     HIP_TRY(hipGetLastError());

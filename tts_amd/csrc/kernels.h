@@ -554,9 +554,9 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
             for (int reg = 0; reg < 16; ++reg) nyq[acc_frame(reg)] = acc[reg];
         }
     }
-    auto phase_at = [&](int64_t fr, int k) -> cf {
+    auto phase_at = [&](int64_t fr, int b, int t, int k) -> cf {
         if (phase_nat) return phase_nat[fr * F + k];
-        return counter_phasor(seed, (uint64_t)((fr + ea.L.frame_origin) * F + k));
+        return drawn_phase(ea.L, seed, b, t, k);
     };
     const int low = (lane >> 3) + 8 * (lane & 7);  // this lane's bin modulo 64 on the frequency side
     for (int h = 0; h < A; ++h) {
@@ -583,13 +583,13 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const int ka = 512 * h + low + 64 * (4 * g + 2 * pp);
-                    const cf pa = phase_at(fr, ka), pb = phase_at(fr, ka + 64);
+                    const cf pa = phase_at(fr, b, t, ka), pb = phase_at(fr, b, t, ka + 64);
                     const float sa2 = s4[2 * pp], sb2 = s4[2 * pp + 1];
                     cf aa = cf{pa.x * sa2 * inv_n, pa.y * sa2 * inv_n};
                     const cf ab = cf{pb.x * sb2 * inv_n, pb.y * sb2 * inv_n};
                     if (ka == 0) {
                         // DC and Nyquist are real and share native bin 0 (c2r ignores their Im)
-                        const cf pn = phase_at(fr, P);
+                        const cf pn = phase_at(fr, b, t, P);
                         aa.y = pn.x * nyq[f] * inv_n;
                     }
                     sp[(4 * h + 2 * g + pp) * 64 + lane] = f4{aa.x, aa.y, ab.x, ab.y};

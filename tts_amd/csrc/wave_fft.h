@@ -147,7 +147,7 @@ struct Dft<4, INV> {
 template <bool INV>
 struct Dft<8, INV> {
     static GLV_HD void run(cf (&v)[8]) {
-        constexpr float h = 0.70710678118654752440f;
+        constexpr float h = 0.70710678118654752440;  // (no f suffix: the double-precision test build wants all digits)
         cf b[4], c[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {

@@ -40,59 +40,71 @@ def _default_compute(mels, mean, std, **kw):
     return griffin_lim_batch(mels, mean, std, **kw)
 
 
-def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=None, **kw):
+# frames one wavefront walks in sharded synthesis: fixed, so that an utterance is cut into the
+# same runs - and gives the same bits - on every device count (the library's automatic run
+# table is fitted to the whole batch a device holds)
+SHARDED_FRAMES_PER_RUN = 32
+
+
+def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=None, seed=0,
+                       frames_per_run=SHARDED_FRAMES_PER_RUN, return_tensors=False, **kw):
     """Batch-sharded synthesis.  `mels` is the full list of (T_i, n_mels) arrays, present on
     every rank.  Each rank synthesises `shard_by_length(...)[rank]` with `compute_fn`
     (default: `griffin_lim_batch` on its GPU) - no communication - and, unless `gather_dst`
-    is None, the padded waveforms are gathered on rank `gather_dst`.
+    is None, ONE gather brings the padded (rows, samples) blocks to rank `gather_dst`: device
+    tensors under RCCL, host tensors under a transport that only moves host memory (gloo).
+
+    Every utterance keeps its identity (its index in `mels`) for the device-drawn initial phase
+    and is cut into runs by a rule that depends on its own length only, so the waveforms are
+    bit-identical for every world size, 1 included.
 
     Returns on the gathering rank (or on every rank if it is not distributed) a list of
-    1-D numpy arrays in the order of `mels`; on other ranks, or with `gather_dst=None`, a
-    dict {global index: 1-D numpy array} of the local results.
+    1-D arrays in the order of `mels` - numpy, or with `return_tensors` views of the gathered
+    tensors where they are; on other ranks, or with `gather_dst=None`, a dict
+    {global index: 1-D array} of the local results.
     """
     compute_fn = compute_fn or _default_compute
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     lengths = [int(m.shape[0]) for m in mels]
-    mine = shard_by_length(lengths, world)[rank]
-    local = {}
-    if mine:
-        audio, n_samples = compute_fn([mels[i] for i in mine], mean, std, **kw)[:2]
-        audio = audio.detach().cpu().numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio)
-        for row, i, n in zip(audio, mine, n_samples):
-            local[i] = np.ascontiguousarray(row[:n])
-    if not distributed:
-        return [local[i] for i in range(len(mels))]
-    if gather_dst is None:
-        return local
-    # one gather of a (max rows, max samples) float32 block per rank; lengths travel as ints
     shards = shard_by_length(lengths, world)
+    mine = shards[rank]
+    hop = kw.get("hop_length", 256)
+    n_out = [hop * (t - 1) for t in lengths]
+    audio = None
+    if mine:
+        audio = compute_fn([mels[i] for i in mine], mean, std, utt_ids=list(mine), seed=seed,
+                           frames_per_run=frames_per_run, **kw)[0]
+        audio = audio.detach() if isinstance(audio, torch.Tensor) else torch.from_numpy(np.asarray(audio))
+
+    def finish(row):
+        return row if return_tensors else row.cpu().numpy()
+
+    local = {i: audio[r, : n_out[i]] for r, i in enumerate(mine)}
+    if not distributed:
+        return [finish(local[i]) for i in range(len(mels))]
+    if gather_dst is None:
+        return {i: finish(v) for i, v in local.items()}
+    # every rank knows all lengths, hence the common block shape: no size exchange
     max_rows = max(len(s) for s in shards)
-    max_len = max((len(v) for v in local.values()), default=0)
-    # RCCL moves device memory only, gloo host memory
+    max_len = max(n_out)
     on_device = dist.get_backend(group) == "nccl"
-    dims = torch.tensor([max_len], dtype=torch.int64, device="cuda" if on_device else "cpu")
-    dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
-    max_len = int(dims.item())
-    block = torch.zeros((max_rows, max_len), dtype=torch.float32)
-    for r, i in enumerate(mine):
-        block[r, : len(local[i])] = torch.from_numpy(local[i])
-    if on_device:
-        block = block.cuda()
+    where = audio.device if (audio is not None and on_device) else (
+        torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
+    block = torch.zeros((max_rows, max_len), dtype=torch.float32, device=where)
+    if audio is not None:
+        block[: audio.shape[0], : audio.shape[1]] = audio[:, :max_len].to(where)
     if rank == gather_dst:
         parts = [torch.empty_like(block) for _ in range(world)]
         dist.gather(block, parts, dst=gather_dst, group=group)
         out = [None] * len(mels)
         for r, idxs in enumerate(shards):
-            rows = parts[r].cpu().numpy()
             for k, i in enumerate(idxs):
-                out[i] = rows[k]
-        # trim every row to its own length: hop*(T-1) is known from the mel alone
-        hop = kw.get("hop_length", 256)
-        return [out[i][: hop * (lengths[i] - 1)] for i in range(len(mels))]
+                out[i] = finish(parts[r][k, : n_out[i]])
+        return out
     dist.gather(block, None, dst=gather_dst, group=group)
-    return local
+    return {i: finish(v) for i, v in local.items()}
 
 
 def split_frames(n_frames, world_size, min_frames=1):

@@ -92,6 +92,23 @@ class GriffinLimPlan:
     def workspace_bytes(self):
         return int(self.lib.glv_plan_workspace_bytes(self._handle))
 
+    def reserve(self, batch, frames, n_iter=60, single_frame=False):
+        """Sets aside the usage-dependent workspace for calls of this shape ahead of time
+        (glv_plan_reserve), so that none of them has to grow it and drain the stream."""
+        _lib.check(self.lib.glv_plan_reserve(self._handle, int(batch), int(frames), int(n_iter),
+                                             int(bool(single_frame)), _stream_ptr(self.device)))
+
+    def set_utterance_ids(self, ids):
+        """Identities keying the device-drawn initial phase of the following calls: utterance b
+        draws the stream (seed, ids[b]).  None = identify utterances by their row."""
+        if ids is None:
+            _lib.check(self.lib.glv_plan_set_utterance_ids(self._handle, None, 0, _stream_ptr(self.device)))
+            return
+        arr = np.ascontiguousarray(ids, dtype=np.int64)
+        _lib.check(self.lib.glv_plan_set_utterance_ids(
+            self._handle, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), int(arr.shape[0]),
+            _stream_ptr(self.device)))
+
     def last_loop_ms(self):
         ms = ctypes.c_float()
         _lib.check(self.lib.glv_plan_last_loop_ms(self._handle, ctypes.byref(ms)))
@@ -427,6 +444,8 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
     frames = mel.shape[0]
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, 0.0, fmax)
+    plan.set_utterance_ids(None)
+    plan.set_option("frames_per_run", 0)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
     if init_phase is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
@@ -453,14 +472,20 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
 
 def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop_length=256,
                       win_length=2048, n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, phase0=None,
-                      seed=0, inversion="pinv", nnls_steps=200, device=None, return_sc=False,
-                      normalize=True):
+                      seed=0, utt_ids=None, frames_per_run=None, inversion="pinv", nnls_steps=200,
+                      device=None, return_sc=False, normalize=True):
     """Batched mel_to_audio_griffin_lim.
 
     ``mel_db``: (B, T, n_mels) array/tensor (rows past lengths[b] ignored) or a
     list of (T_b, n_mels) arrays.  Returns (audio, n_samples[, sc]) with audio a
     (B, hop*(T_max-1)) device tensor whose row b holds n_samples[b] =
     hop*(lengths[b]-1) samples followed by zeros.
+
+    ``utt_ids``: one integer per utterance keying its device-drawn initial phase (``phase0`` None):
+    utterance b draws the stream (seed, utt_ids[b]); default: its row.  With ids that travel with
+    the utterances and a fixed ``frames_per_run`` (the number of frames one wavefront walks; the
+    default None lets the library fit the run table to the whole batch) an utterance's waveform
+    is bit-identical whatever batch, row or device it is synthesised in.
     """
     if isinstance(mel_db, (list, tuple)):
         lengths = [int(m.shape[0]) for m in mel_db]
@@ -483,6 +508,8 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
         lengths = [t_max] * b
     plan = get_plan(n_fft, hop_length, win_length, n_mels, t_max, b, device)
     plan.set_mel_basis(sr, 0.0, fmax)
+    plan.set_utterance_ids(utt_ids)
+    plan.set_option("frames_per_run", 0 if frames_per_run is None else int(frames_per_run))
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous()
     n_samples = [hop_length * (int(n) - 1) for n in lengths]
     if inversion == "pinv":
@@ -518,6 +545,8 @@ def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_len
     hop_length = win_length // 4 if hop_length is None else hop_length
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, fmin, fmax)
+    plan.set_utterance_ids(None)
+    plan.set_option("frames_per_run", 0)
     mel_tm = mel.t().to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
     S = plan.mel_invert_nnls(mel_tm, n_steps=n_steps, power=power)
     if init_phase is None:
