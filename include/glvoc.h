@@ -164,6 +164,23 @@ int glv_mel_to_audio(glv_plan* plan, const float* mel_db_dev, float mean, float 
 int glv_peak_normalize(glv_plan* plan, float* y_dev, const int* n_samples_host, int batch,
                        int64_t y_stride, float eps, void* stream);
 
+/*
+ * glv_peak_normalize for callers that cannot allocate device memory or hold a plan: code under
+ * hipGraph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  Same arithmetic and the same bits as glv_peak_normalize; the differences:
+ *   - no plan: it runs on the CURRENT device, on `stream`;
+ *   - the row lengths are read on the device: n_samples_dev is device memory, (batch) int32,
+ *     0 <= n_samples_dev[b] <= y_stride (not checked);
+ *   - the per-row maxima live in a fixed device array inside the library (128 KiB per GPU, held
+ *     until the process ends), so batch <= 32768; larger batches are refused with
+ *     GLV_ERR_INVALID;
+ *   - it calls no hipMalloc / hipFree and takes no lock on the device.
+ * Every call on a GPU uses that GPU's one array: calls that overlap in time on one GPU (two
+ * streams, two threads) race on it - serialise them.
+ */
+int glv_peak_normalize_noalloc(float* y_dev, const int* n_samples_dev, int batch, int64_t y_stride,
+                               float eps, void* stream);
+
 /* The two halves of glv_peak_normalize, for callers that must combine the peak of
  * several pieces first (time-sharded synthesis takes the maximum over ranks in between):
  * peak_dev[b] = max|y[b, :n_samples[b]]|, then y[b] /= (peak_dev[b] + eps). */

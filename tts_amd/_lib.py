@@ -45,6 +45,8 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_peak_normalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
+    "glv_peak_normalize_noalloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
     "glv_peak_reduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_peak_scale": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1261,6 +1262,57 @@ extern "C" int glv_peak_normalize(glv_plan* p, float* y_dev, const int* n_sample
     if (rc != GLV_OK) return rc;
     return glv_peak_scale(p, y_dev, n_samples_host, batch, y_stride, reinterpret_cast<const float*>(p->d_peak),
                           eps, stream);
+}
+
+// ---------------------------------------------------------------------------
+// peak normalisation for callers that cannot allocate
+// ---------------------------------------------------------------------------
+// Per-row maxima of glv_peak_normalize_noalloc: device memory that exists from the moment the
+// library is loaded, one copy per GPU, so the call needs neither a plan nor an allocation.
+#define GLV_NOALLOC_MAX_BATCH 32768
+static __device__ __align__(256) unsigned scratch[GLV_NOALLOC_MAX_BATCH];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on every GPU seen so far
+std::mutex g_scratch_mutex;
+
+// The array's name is a host-side handle, not a device address: the address each GPU holds its
+// copy at is looked up once per device, with that device current.
+int scratch_for_current_device(unsigned** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(GLV_ERR_UNSUPPORTED, "device index %d not supported", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        unsigned* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(GLV_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return GLV_OK;
+}
+}  // namespace
+
+extern "C" int glv_peak_normalize_noalloc(float* y_dev, const int* n_samples_dev, int batch, int64_t y_stride,
+                                          float eps, void* stream) {
+    if (!y_dev || !n_samples_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (batch < 1 || batch > GLV_NOALLOC_MAX_BATCH)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]: glv_peak_normalize_noalloc keeps its per-row maxima "
+                    "in a fixed device array; use glv_peak_normalize for larger batches", batch, GLV_NOALLOC_MAX_BATCH);
+    if (y_stride < 1) return fail(GLV_ERR_INVALID, "y_stride must be >= 1");
+    unsigned* peaks = nullptr;
+    int rc = scratch_for_current_device(&peaks);
+    if (rc != GLV_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // the array keeps the previous call's maxima; 0 bits is the identity of the maximum
+    HIP_TRY(hipMemsetAsync(peaks, 0, sizeof(unsigned) * batch, st));
+    const dim3 grid(std::min<unsigned>(grid_for(y_stride, 256 * 8), 64), batch);
+    hipLaunchKernelGGL(peak_reduce_kernel, grid, dim3(256), 0, st, y_dev, y_stride, n_samples_dev, peaks);
+    hipLaunchKernelGGL(peak_scale_kernel, grid, dim3(256), 0, st, y_dev, y_stride, n_samples_dev, peaks, eps, 0);
+    HIP_TRY(hipGetLastError());
+    return GLV_OK;
 }
 
 extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
