@@ -57,6 +57,9 @@ def main():
             if text.startswith("{") and '"roofline"' in text:
                 roof = json.loads(text)["roofline"]
                 summary["bench_under_profiler_us_per_launch"] = roof["kernel_ms_per_launch"] * 1e3
+                # which workload, variant and kernel sources these counters belong to
+                summary["traffic_key"] = roof.get("traffic_key")
+                summary["engine_source_digest"] = roof.get("engine_source_digest")
                 lines += ["## the profiled process's own measurement", "",
                           f"HIP events around the {roof['kernel']} launches, in the same process the table above was "
                           f"taken from: {roof['kernel_ms_per_launch'] * 1e3:.2f} us per launch (kernel-trace serialises "
@@ -85,7 +88,8 @@ def main():
             rd, wr = 2 * f * 1024 / 1e6, w * 1024 / 1e6
             lines.append(f"| {k} | {f:.0f} | {w:.0f} | {rd:.2f} | {wr:.2f} | {rd + wr:.2f} |")
             # the iteration kernel: MODE_ITER_LIN (8) by default, MODE_ITER (0) with option linear = 0
-            if "gl_engine_kernel" in k and k.rstrip(">").endswith(("8, false", "0, false")):
+            if "gl_engine_kernel" in k and k.rstrip(">").endswith(("8, false", "0, false", "6, false", "4, false")):
+                summary["gl_engine_iter_kernel"] = k
                 summary["gl_engine_iter_bytes_per_launch"] = int((rd + wr) * 1e6)
                 summary["gl_engine_iter_read_bytes"] = int(rd * 1e6)
                 summary["gl_engine_iter_write_bytes"] = int(wr * 1e6)
