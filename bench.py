@@ -315,7 +315,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert args.traffic_only or args.alias_utts or bool(torch.isfinite(out).all()), "non-finite audio"
+    # (GLV_BENCH_NO_CHECK: timing-only experiment builds of the library produce garbage)
+    assert (args.traffic_only or args.alias_utts or os.environ.get("GLV_BENCH_NO_CHECK")
+            or bool(torch.isfinite(out).all())), "non-finite audio"
 
     if rank == 0:
         # whole-job audio: config 3 counts every utterance once, config 1 a batch per rank

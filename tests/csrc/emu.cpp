@@ -59,14 +59,16 @@ void emu_launch(const IterArgs& a) {
         }
         constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
         constexpr int kRcArg = MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0);
-        if (MODE == MODE_ITER_LIN)
+        constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z;
+        constexpr int kNzh = MODE == MODE_ITER_LIN_Z ? Eng::NP / 2 : Eng::NP;
+        if (kLin)
             for (int l = 0; l < 64; ++l) {
                 e[l].template preload_lin<SC>(a);
                 e[l].prefetch_block(a, run.t_begin);
                 e[l].prefetch_block_prev(a, run.t_begin);
-                e[l].prefetch_s(a, run.t_begin);
+                e[l].template prefetch_s_pair<kNzh>(a, run.t_begin);
             }
-        if (MODE != MODE_ISTFT && MODE != MODE_ITER_LIN)
+        if (MODE != MODE_ISTFT && !kLin)
             for (int l = 0; l < 64; ++l) {
                 e[l].preload(a);
                 e[l].prefetch_block(a, run.t_begin);
@@ -89,15 +91,15 @@ void emu_launch(const IterArgs& a) {
                 for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph3_prev(b0.data());
             }
-            if (MODE == MODE_ITER_LIN) {
+            if (kLin) {
                 for (int l = 0; l < 64; ++l) e[l].template lin_advance<SC>(a, t);
                 if (SC) {
                     for (int l = 0; l < 64; ++l) e[l].lin_window_signal(b0.data());
                     for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
                     for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
                     for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
-                    for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
-                    for (int l = 0; l < 64; ++l) e[l].ph3_metric(b0.data());
+                    for (int l = 0; l < 64; ++l) e[l].pair_store(b0.data());
+                    for (int l = 0; l < 64; ++l) e[l].ph3_metric_pair(b0.data());
                 }
                 for (int l = 0; l < 64; ++l) {
                     e[l].lin_window_combined(b0.data());
@@ -106,8 +108,14 @@ void emu_launch(const IterArgs& a) {
                 for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph1_write(b1.data());
                 for (int l = 0; l < 64; ++l) e[l].ph2_read(b1.data());
-                for (int l = 0; l < 64; ++l) e[l].ph2_write(b0.data());
-                for (int l = 0; l < 64; ++l) e[l].template ph3_update<false, 2>(a, t, b0.data());
+                for (int l = 0; l < 64; ++l) e[l].pair_store(b0.data());
+                // (reads the partners from one buffer, sends them their results through the other)
+                for (int l = 0; l < 64; ++l) e[l].template ph3_pair<kNzh>(a, t, b0.data(), b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph4_pair(b1.data(), b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph5_read(b0.data());
+                for (int l = 0; l < 64; ++l) e[l].ph5_write(b1.data());
+                for (int l = 0; l < 64; ++l) e[l].ph6(a, t, b1.data());
+                continue;
             } else if (MODE != MODE_ISTFT) {
                 for (int l = 0; l < 64; ++l) e[l].ph0(a, t, b0.data());
                 for (int l = 0; l < 64; ++l) e[l].ph1_read(b0.data());
@@ -265,7 +273,10 @@ struct Emu {
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
-                   float* y, int64_t y_stride, float* sc, bool recompute, bool linear = false) {
+                   float* y, int64_t y_stride, float* sc, bool recompute, int linear = 0) {
+        // linear: 1 = momentum in the time domain (magnitudes in pair order), 2 = the same with
+        // the upper quarter of every lane's bins known to be zero
+        L.s_pair_nzh = linear == 1 ? 4 * A : (linear == 2 ? 2 * A : 0);
         for (int b = 0; b < batch; ++b)
             for (int t = 0; t < nf[b]; ++t)
                 for (int q = 0; q < P; ++q)
@@ -286,8 +297,13 @@ struct Emu {
                 io(cur, out);
                 a.y_prev = ym[prev].data();
                 a.y_prev_tail = yt[prev].data();
-                if (sc) emu_launch<A, HB, MODE_ITER_LIN, true>(a);
-                else emu_launch<A, HB, MODE_ITER_LIN, false>(a);
+                if (linear == 2) {
+                    if (sc) emu_launch<A, HB, MODE_ITER_LIN_Z, true>(a);
+                    else emu_launch<A, HB, MODE_ITER_LIN_Z, false>(a);
+                } else {
+                    if (sc) emu_launch<A, HB, MODE_ITER_LIN, true>(a);
+                    else emu_launch<A, HB, MODE_ITER_LIN, false>(a);
+                }
                 cur = out;
             } else if (recompute) {
                 const int out = (cur + 1) % 3, prev = (cur + 2) % 3;
@@ -377,12 +393,14 @@ int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const flo
                    uint64_t seed, const int* n_frames, int batch, int frames_stride, int n_iter,
                    float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc, int recompute) {
     // recompute: 0 = run-based iteration, 1 = its recompute-the-previous-spectrum variant,
-    //            2 = one frame per wave, 3 = momentum in the time domain
+    //            2 = one frame per wave, 3 = momentum in the time domain, 4 = the same with the
+    //            magnitudes of the upper quarter of every lane's registers known to be zero
     return dispatch(n_fft, hop, [&](auto* tag) {
         using E = std::remove_pointer_t<decltype(tag)>;
         E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
         if (recompute == 2) return e.griffinlim_single(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
-        if (recompute == 3) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, true);
+        if (recompute == 3) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 1);
+        if (recompute == 4) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 2);
         return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, recompute != 0);
     });
 }

@@ -297,3 +297,28 @@ def test_double_precision_engine_is_librosas_iteration(emu64, lj001, n_fft, fram
         assert rel_l2(got, want[k]) < (1e-13 if k == 4 else 1e-9), k
     y32 = O.griffinlim(s32, n_iter=60, hop_length=256, win_length=n_fft, init_phase=ph.astype(np.complex64))
     print(f"oracle fp32 vs oracle fp64 at k=60, n_fft {n_fft}: {rel_l2(y32, want[60]):.2e}")
+
+
+@pytest.mark.parametrize("n_fft,hop,win,frames,fpr", [(1024, 256, 1024, 23, 7), (2048, 256, 2048, 26, 9),
+                                                      (2048, 512, 2048, 17, 5), (1024, 128, 1024, 30, 9),
+                                                      (1024, 256, 1024, 2, 8)])
+def test_zero_magnitude_bins_are_left_out(emu, n_fft, hop, win, frames, fpr):
+    """Magnitudes that vanish from bin 3/4 * n_fft/2 on (what a mel basis ending below the Nyquist
+    frequency gives the reference's pinv product): the iteration that neither fetches nor updates
+    those bins (mode 4) is the oracle's iteration, waveform and convergence curve, and agrees
+    with the full pair-order iteration (mode 3) to rounding."""
+    rng = np.random.default_rng(300 + frames)
+    f = n_fft // 2 + 1
+    s = (rng.standard_normal((f, frames)) ** 2).astype(np.float32)
+    s[::7] *= -0.3
+    s[3 * (n_fft // 2) // 4:] = 0.0
+    ph = np.exp(2j * np.pi * rng.random((f, frames))).astype(np.complex64)
+    y_ref, sc_ref = O.griffinlim(s, n_iter=5, hop_length=hop, win_length=win, init_phase=ph, return_sc=True)
+    y4, sc4 = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr, recompute=4)
+    y3, sc3 = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr, recompute=3)
+    assert rel_l2(y4[0], y_ref) < 1e-5
+    assert rel_l2(y4[0], y3[0]) < 1e-6
+    assert np.max(np.abs(sc4[0] - sc_ref) / sc_ref) < 1e-5
+    y4n, _ = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr, recompute=4,
+                            want_sc=False)
+    assert np.array_equal(y4, y4n)

@@ -16,6 +16,8 @@ struct LayoutArgs {
     int64_t frame_origin;     // global index of local frame 0 (time shard), else 0
     const int64_t* utt_ids;   // [batch] identity of every utterance for the device-drawn phase, or
                               // null: its position in the batch
+    int s_pair_nzh;           // 0: magnitudes in native order; else pair order (pair_s_slot) with
+                              // that many possibly non-zero mirrors per lane
 };
 
 // Device-drawn initial phase of (utterance b, frame t, bin k): the stream is keyed by the
@@ -39,7 +41,8 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
     const float* srow = S_nat + fr * L.F;
     float* snat = S_native + fr * (L.P + 4);
     const float s = srow[k];
-    snat[native_s_index(reg, lane)] = s;
+    const int slot = L.s_pair_nzh ? pair_s_slot<A>(L.s_pair_nzh, reg, lane) : native_s_index(reg, lane);
+    if (slot >= 0) snat[slot] = s;
     auto phase_at = [&](int kk) -> cf {
         if (phase_nat) return phase_nat[fr * L.F + kk];
         return drawn_phase(L, seed, b, t, kk);
@@ -49,7 +52,8 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
     if (q == 0) {
         const float s_nyq = srow[L.P];
         snat[L.P] = s_nyq;
-        snat[L.P + 1] = snat[L.P + 2] = snat[L.P + 3] = 0.f;
+        if (!L.s_pair_nzh) snat[L.P + 1] = 0.f;  // pair order keeps the bin P/2 there
+        snat[L.P + 2] = snat[L.P + 3] = 0.f;
         const cf pn = phase_at(L.P);
         ang = cf{p.x * s * inv_n, pn.x * s_nyq * inv_n};  // c2r ignores Im of DC / Nyquist
     }

@@ -73,6 +73,11 @@ struct RunDesc {
 // signal replaces the spectrum state (read 8P, write 8P bytes per frame) by one more read of
 // H samples.  Same arithmetic up to rounding; the convergence metric, which needs |rebuilt_k|
 // itself, costs a second forward transform only when it is asked for.
+// The split and the phase update of MODE_ITER_LIN work on mirror pairs of bins (wave_fft.h, "the
+// split done on mirror PAIRS"), with the target magnitudes stored in PAIR ORDER (pair_s_slot).
+// MODE_ITER_LIN_Z is the same for magnitudes known to vanish in the upper quarter of every
+// lane's registers (a mel basis that ends below the Nyquist frequency makes its pseudo-inverse,
+// and so the magnitudes, exactly zero there): those bins are neither fetched nor updated.
 // MODE_ITER1 / MODE_ISTFT1: one frame per wave, for batches too small to fill the device with
 // runs.  There is no running sum: a frame's windowed output goes, as R whole blocks, to
 // partial-sum buffer (t mod R), and a reader adds the R buffers (see load_frame_from_parts).
@@ -85,7 +90,8 @@ enum Mode {
     MODE_ITER_RC_FIRST = 5,
     MODE_ITER1 = 6,
     MODE_ISTFT1 = 7,
-    MODE_ITER_LIN = 8
+    MODE_ITER_LIN = 8,
+    MODE_ITER_LIN_Z = 9
 };
 
 struct IterArgs {
@@ -217,6 +223,7 @@ struct Engine {
     cf tp_n[E];
     float s_n[E];
     float s_nyq_n;
+    float s_mid_n;  // pair order: magnitude of the self-mirrored bin P/2 (used by lane 0)
     int mbase;
     int lane;
     RunDesc run;
@@ -635,6 +642,167 @@ struct Engine {
         else
             prefetch_s(a, t + 1);
     }
+    // ---- MODE_ITER_LIN / MODE_ITER_LIN_Z: split, phase update and inverse split on mirror pairs ----
+    static constexpr int NP = E / 2;
+    // magnitudes in pair order: s_n[i] = pair i's own bin, s_n[NP + i] = its mirror; NZH = how many
+    // of the mirrors (the last NZH pairs) can be non-zero
+    template <int NZH>
+    GLV_HD void prefetch_s_pair(const IterArgs& a, int t) {
+        const int tt = t < run.t_end ? t : run.t_end - 1;
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
+#pragma unroll
+        for (int g = 0; g < NP / 4; ++g) {
+            const f4 sq = ld_stream(reinterpret_cast<const f4*>(sf) + g * 64 + lane);
+            s_n[4 * g] = sq.x;
+            s_n[4 * g + 1] = sq.y;
+            s_n[4 * g + 2] = sq.z;
+            s_n[4 * g + 3] = sq.w;
+        }
+        const float* hi = sf + NP * 64;
+        constexpr int first = NP + (NP - NZH);
+        if (NZH % 4 == 0) {
+#pragma unroll
+            for (int g = 0; g < NZH / 4; ++g) {
+                const f4 sq = ld_stream(reinterpret_cast<const f4*>(hi) + g * 64 + lane);
+                s_n[first + 4 * g] = sq.x;
+                s_n[first + 4 * g + 1] = sq.y;
+                s_n[first + 4 * g + 2] = sq.z;
+                s_n[first + 4 * g + 3] = sq.w;
+            }
+        } else {
+            static_assert(NZH % 4 == 0 || NZH == 2, "the mirrors are stored four or two to a lane");
+            const cf sq = ld_stream(reinterpret_cast<const cf*>(hi) + lane);
+            s_n[first] = sq.x;
+            s_n[first + 1] = sq.y;
+        }
+#pragma unroll
+        for (int i = NP; i < first; ++i) s_n[i] = 0.f;
+        s_nyq_n = sf[P];
+        s_mid_n = sf[P + 1];
+    }
+    // angles / (|angles| + tiny) * S, pre-scaled by 1 / n_fft, of one complex bin
+    GLV_HD cf unit_times(cf d, float sv, float inv_n) const {
+        const float k = inv_norm(d.x * d.x + d.y * d.y) * inv_n * sv;
+        return cf{d.x * k, d.y * k};
+    }
+    GLV_HD void sc_add(cf x, float sv) {
+        const float e = sqrtf(x.x * x.x + x.y * x.y) - fabsf(sv);
+        sc_num += e * e;
+        sc_den += sv * sv;
+    }
+    // lane 0's two real bins, DC and Nyquist, packed as (re, im)
+    GLV_HD void sc_add_packed(cf x, float sx, float sy) {
+        const float ex = fabsf(x.x) - fabsf(sx), ey = fabsf(x.y) - fabsf(sy);
+        sc_num += ex * ex + ey * ey;
+        sc_den += sx * sx + sy * sy;
+    }
+    // the spectrum of the signal itself, for the convergence metric only (all bins count, also
+    // those whose target is zero)
+    GLV_HD void ph3_metric_pair(const cf* r) {
+        const cf* twp = twp_regs();
+#pragma unroll
+        for (int i0 = 0; i0 < NP; i0 += CH / 2) {
+            cf m[CH / 2], tw[CH / 2];
+            F::template pair_partners<CH / 2>(m, r, mbase, i0);
+            load_twp_pairs(tw, twp, i0);
+#pragma unroll
+            for (int j = 0; j < CH / 2; ++j) {
+                const int i = i0 + j;
+                const cf a = v[i];
+                cf xk, xm;
+                F::pair_fwd(a, m[j], tw[j], xk, xm);
+                if (i == 0) {
+                    if (lane == 0) {
+                        sc_add_packed(cf{a.x + a.y, a.x - a.y}, s_n[0], s_nyq_n);
+                        // the self-mirrored bin: X[P/2] = conj(Z[P/2])
+                        sc_add(v[NP], s_mid_n);
+                    } else {
+                        sc_add(xk, s_n[0]);
+                        sc_add(xm, s_n[NP]);
+                    }
+                } else {
+                    sc_add(xk, s_n[i]);
+                    sc_add(xm, s_n[NP + i]);
+                }
+            }
+            if (CH < E) GLV_SCHED_FENCE();
+        }
+    }
+    // this lane's twiddles 0.5 W_N^k of pairs i0 .. i0+NQ-1
+    template <int NQ>
+    GLV_HD void load_twp_pairs(cf (&tw)[NQ], const cf* twp, int i0) const {
+        static_assert(NQ % 2 == 0, "table entries are fetched in pairs");
+        if (twp) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) tw[j] = twp[i0 + j];
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < NQ / 2; ++kp) G::load2(tab.twP, i0 / 2 + kp, lane, tw[2 * kp], tw[2 * kp + 1]);
+        }
+    }
+    // v = forward transform of y_k - c y_{k-1}, partners published in r.  Leaves the low
+    // registers of v holding the inverse split's result and sends the partners theirs through w
+    // (the same buffer on the device: a wave's LDS reads complete before its later writes).
+    template <int NZH>
+    GLV_HD void ph3_pair(const IterArgs& a, int t, const cf* r, cf* w) {
+        const cf* twp = twp_regs();
+        // lane 0's self-mirrored bin P/2: X = conj(Z), Z' = 2 conj(X')
+        const cf zmid = v[NP];
+        const cf xmid = unit_times(cf{zmid.x, -zmid.y}, s_mid_n, a.inv_n);
+        const cf zmid_new = cf{2.0f * xmid.x, -2.0f * xmid.y};
+#pragma unroll
+        for (int i0 = 0; i0 < NP; i0 += CH / 2) {
+            cf m[CH / 2], tw[CH / 2];
+            F::template pair_partners<CH / 2>(m, r, mbase, i0);
+            load_twp_pairs(tw, twp, i0);
+#pragma unroll
+            for (int j = 0; j < CH / 2; ++j) {
+                const int i = i0 + j;
+                const bool has_hi = i >= NP - NZH;  // the mirror's magnitude can be non-zero
+                const cf za = v[i];
+                cf xk, xm = cf{0.f, 0.f};
+                if (has_hi)
+                    F::pair_fwd(za, m[j], tw[j], xk, xm);
+                else
+                    xk = F::pair_fwd_low(za, m[j], tw[j]);
+                cf yk = unit_times(xk, s_n[i], a.inv_n), ym = cf{0.f, 0.f};
+                if (has_hi) ym = unit_times(xm, s_n[NP + i], a.inv_n);
+                if (i == 0) {
+                    // lane 0 holds the two real bins DC and Nyquist here
+                    const cf x0 = cf{za.x + za.y, za.x - za.y};
+                    const float px = rcp_refined(fabsf(x0.x) + kTiny) * a.inv_n;
+                    const float py = rcp_refined(fabsf(x0.y) + kTiny) * a.inv_n;
+                    const cf y0 = cf{x0.x * px * s_n[0], x0.y * py * s_nyq_n};
+                    const bool packed = lane == 0;
+                    yk = packed ? y0 : yk;
+                    if (has_hi) ym = packed ? cf{0.f, 0.f} : ym;
+                }
+                cf zk, zm;
+                if (has_hi)
+                    F::pair_inv(yk, ym, tw[j], zk, zm);
+                else
+                    F::pair_inv_low_only(yk, tw[j], zk, zm);
+                if (i == 0) {
+                    const bool packed = lane == 0;
+                    zk = packed ? cf{yk.x + yk.y, yk.x - yk.y} : zk;
+                }
+                v[i] = zk;
+                F::pair_send(zm, w, mbase, i);
+            }
+            if (CH < E) GLV_SCHED_FENCE();
+        }
+        // nobody else writes row 0 of lane 0's column (its own pairs send to rows 1 ..), so the
+        // self-mirrored bin travels the same way as every other high register
+        if (lane == 0) w[0] = zmid_new;
+        prefetch_s_pair<NZH>(a, t + 1);
+    }
+    GLV_HD void pair_store(cf* w) { F::pair_store(v, w, lane); }
+    // own high registers back from the partners, then the first inverse pass
+    GLV_HD void ph4_pair(const cf* r, cf* w) {
+        F::pair_receive(v, r, lane);
+        F::inv_c(v, tab, w, lane);
+    }
+
     // ---- MODE_TRAFFIC: one frame's memory operations, nothing else ----
     GLV_HD void traffic_frame(const IterArgs& a, int t) {
         cf nb[E];
@@ -811,6 +979,33 @@ GLV_HD int native_bin(int q) {
 // index of (reg, lane) inside a native spectrum frame (cf units) and S frame (floats)
 GLV_HD int native_spec_index(int reg, int lane) { return ((reg >> 1) * 64 + lane) * 2 + (reg & 1); }
 GLV_HD int native_s_index(int reg, int lane) { return ((reg >> 2) * 64 + lane) * 4 + (reg & 3); }
+
+// PAIR ORDER of the target magnitudes (MODE_ITER_LIN*): where the magnitude of the bin at native
+// position (reg, lane) sits inside a frame of P + 4 floats, or -1 if it has no slot because it is
+// zero by construction.  A lane's own low registers come first, [reg / 4][lane][4] as in native
+// order; then, for the pairs NP - nzh .. NP - 1 of every lane, the magnitude of the pair's mirror
+// bin, [..][lane][4] (or [lane][2] when nzh is 2); the Nyquist bin at [P], the self-mirrored bin
+// P/2 at [P + 1].
+template <int A>
+GLV_HD int pair_s_slot(int nzh, int reg, int lane) {
+    constexpr int E = Geo<A>::E, NP = E / 2, P = Geo<A>::P;
+    if (reg < NP) return native_s_index(reg, lane);
+    const int low = (lane >> 3) + 8 * (lane & 7);
+    int owner, i;
+    if (low == 0) {
+        if (reg == NP) return P + 1;
+        owner = 0;
+        i = E - reg;
+    } else {
+        const int lp = 64 - low;
+        owner = 8 * (lp & 7) + (lp >> 3);
+        i = E - 1 - reg;
+    }
+    const int h = i - (NP - nzh);
+    if (h < 0) return -1;
+    const int base = NP * 64;
+    return (nzh % 4 == 0) ? base + ((h >> 2) * 64 + owner) * 4 + (h & 3) : base + owner * 2 + h;
+}
 
 // Initial phase drawn on the device: the stand-in for librosa's unseeded default_rng when the
 // caller supplies no phase.  A counter-based generator (two rounds of a 32-bit

@@ -58,6 +58,9 @@ struct glv_plan {
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
     int recompute = 0;     // iterate without the spectrum state in HBM (MODE_ITER_RC)
     int alias_utts = 0;    // measurement aid: all utterances share one utterance's memory
+    int zero_skip = 1;     // leave out the bins whose inverse-basis rows vanish (MODE_ITER_LIN_Z)
+    int kmax_bin = 1 << 30;  // highest bin with a non-zero row in the inverse basis
+    int cur_nzh = 0;       // pair-order parameter of the call in progress (0: native order)
     int linear = 1;        // momentum term formed in the time domain (MODE_ITER_LIN): no spectrum state
                            // in memory; 0 = in the frequency domain as librosa writes it (MODE_ITER)
     int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
@@ -119,12 +122,12 @@ struct glv_plan {
     // graph cache for the iteration loop: the most recently used shapes stay instantiated, so a
     // serving loop that alternates between a few batch shapes replays instead of re-capturing
     struct GraphKey {
-        int n_runs, n_iter, with_sc, frames_stride, batch, single;
+        int n_runs, n_iter, with_sc, frames_stride, batch, single, nzh;
         float cmom;
         bool operator==(const GraphKey& o) const {
             return n_runs == o.n_runs && n_iter == o.n_iter && with_sc == o.with_sc &&
                    frames_stride == o.frames_stride && batch == o.batch && single == o.single &&
-                   cmom == o.cmom;
+                   nzh == o.nzh && cmom == o.cmom;
         }
     };
     struct GraphEntry {
@@ -188,6 +191,11 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_LIN_Z) {
+        if (sc)
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, true>), g, b, lds, st, a);
+        else
+            hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT1) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT1, false>), g, b, lds, st, a);
     } else {
@@ -627,6 +635,8 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     } else if (!strcmp(name, "linear")) {
         p->linear = value != 0;
         drop_graphs(p);
+    } else if (!strcmp(name, "zero_skip")) {
+        p->zero_skip = value != 0;
     } else if (!strcmp(name, "single_frame")) {
         if (value < -1 || value > 1) return fail(GLV_ERR_INVALID, "single_frame must be -1 (automatic), 0 or 1");
         p->single_frame = value;
@@ -702,6 +712,13 @@ extern "C" int glv_plan_set_inverse_basis(glv_plan* p, const float* pinv_host) {
     for (int f = 0; f < p->F; ++f)
         for (int m = 0; m < p->n_mels; ++m) t[(size_t)m * p->Fp + f] = pinv_host[(size_t)f * p->n_mels + m];
     HIP_TRY(hipMemcpy(p->d_pinv_t, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+    // A mel basis that ends below the Nyquist frequency has all-zero columns above its last
+    // filter, its pseudo-inverse all-zero rows: the magnitudes of those bins are exactly zero
+    // for every mel, and the iteration can leave them out.
+    p->kmax_bin = 0;
+    for (int f = 0; f < p->F; ++f)
+        for (int m = 0; m < p->n_mels; ++m)
+            if (pinv_host[(size_t)f * p->n_mels + m] != 0.f) p->kmax_bin = f;
     p->have_pinv = true;
     return GLV_OK;
 }
@@ -767,6 +784,16 @@ extern "C" int glv_mel_invert_nnls(glv_plan* p, const float* mel_dev, int batch,
 
 namespace {
 
+// Mirrors per lane whose magnitude can be non-zero (pair order, engine.h): all E/2 = 4A of them,
+// or only the upper half when every bin from the first one of register 3E/4 on has an all-zero
+// row in the inverse basis (and the magnitudes are this basis times a mel).
+int pair_nzh(const glv_plan* p, bool magnitudes_from_basis) {
+    const int E = 8 * p->A, q = E / 2 + E / 4;
+    const int first_zero_bin = 64 * (q & 7) + 512 * (q >> 3);
+    const bool quarter = magnitudes_from_basis && p->zero_skip && p->have_pinv && p->kmax_bin < first_zero_bin;
+    return quarter ? E / 4 : E / 2;
+}
+
 // enqueues the n_iter iteration kernels (and nothing else) on st; *last receives the index
 // of the overlap-add generation the final iteration wrote
 // the loop rotates three signal generations (instead of two) in the variants that read the
@@ -801,7 +828,8 @@ int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool wi
             set_io(p, a, cur, out);
             a.y_prev = p->d_ym[prev];
             a.y_prev_tail = p->d_yt[prev];
-            HIP_TRY(p->launch_engine(MODE_ITER_LIN, with_sc, a, engine_grid(p), st));
+            HIP_TRY(p->launch_engine(p->cur_nzh == 4 * p->A ? MODE_ITER_LIN : MODE_ITER_LIN_Z, with_sc, a,
+                                     engine_grid(p), st));
             cur = out;
         } else if (p->recompute && !p->traffic_only) {
             // three generations rotate: read `cur` (and the one before it), write the next
@@ -874,7 +902,12 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         rc = ensure_sc(p, (size_t)n_iter * p->n_runs * 2, st);
         if (rc != GLV_OK) return rc;
     }
+    // The time-domain-momentum iteration keeps the magnitudes in pair order; with magnitudes that
+    // come from this plan's inverse basis it also knows which bins are zero for good.
+    const bool lin_runs = !single && three_generations(p) && !p->recompute;
+    p->cur_nzh = lin_runs ? pair_nzh(p, src.mel_db_dev != nullptr) : 0;
     ElemArgs ea = elem_args(p, batch, frames_stride);
+    ea.L.s_pair_nzh = p->cur_nzh;
     const float inv_n = 1.0f / (float)p->n_fft;
     if (src.S_dev) {
         p->launch_init(ea, src.S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec,
@@ -900,7 +933,7 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (n_iter > 0) {
         if (p->use_graph) {
             const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch,
-                                         single ? 1 : 0, cmom};
+                                         single ? 1 : 0, p->cur_nzh, cmom};
             glv_plan::GraphEntry* hit = nullptr;
             for (auto& g : p->graphs)
                 if (g.key == key) hit = &g;
@@ -1097,6 +1130,8 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     ea.L.frames_local = frames_local;
     ea.L.frame_origin = t0;
     ea.L.utt_ids = nullptr;  // one utterance: its phase stream is keyed by the seed alone
+    p->cur_nzh = p->linear ? 4 * p->A : 0;
+    ea.L.s_pair_nzh = p->cur_nzh;
     p->launch_init(ea, S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, 1.0f / (float)p->n_fft, p->d_S,
                    p->d_spec, st);
     HIP_TRY(hipGetLastError());

@@ -56,7 +56,7 @@ __device__ __forceinline__ void wave_sync() {
 // measurement build: every wave of the iteration kernel leaves four time stamps (100 MHz clock)
 __device__ unsigned long long glv_wave_times[20 * 16384];
 #define GLV_STAMP(k)                                                                          \
-    if ((MODE == MODE_ITER_LIN || MODE == MODE_ITER1) && (threadIdx.x & 63) == 0) {           \
+    if ((MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ITER1) && (threadIdx.x & 63) == 0) {           \
         const int w_ = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);                      \
         if (w_ < 16384 && (k) < 20) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
     }
@@ -144,7 +144,9 @@ gl_engine_kernel(IterArgs a) {
         e.ph6_single(a, t, xb);
         GLV_STAMP(3)
     }
-    constexpr bool kLin = MODE == MODE_ITER_LIN;
+    constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z;
+    // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
+    constexpr int kNzh = MODE == MODE_ITER_LIN_Z ? Eng::NP / 2 : Eng::NP;
     if (!kSingle && !kLin && MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
@@ -153,11 +155,11 @@ gl_engine_kernel(IterArgs a) {
         e.preload_prev(a);
         e.prefetch_block_prev(a, e.run.t_begin);
     }
-    if (MODE == MODE_ITER_LIN) {
+    if (kLin) {
         e.template preload_lin<SC>(a);
         e.prefetch_block(a, e.run.t_begin);
         e.prefetch_block_prev(a, e.run.t_begin);
-        e.prefetch_s(a, e.run.t_begin);
+        e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
     }
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     if (kRc) e.prefetch_s(a, e.run.t_begin);
@@ -206,9 +208,9 @@ gl_engine_kernel(IterArgs a) {
                 wave_sync();
                 e.ph2_read(xb);
                 wave_sync();
-                e.ph2_write(xb);
+                e.pair_store(xb);
                 wave_sync();
-                e.ph3_metric(xb);
+                e.ph3_metric_pair(xb);
                 wave_sync();
             }
             e.lin_window_combined(xb);
@@ -220,10 +222,21 @@ gl_engine_kernel(IterArgs a) {
             wave_sync();
             e.ph2_read(xb);
             wave_sync();
-            e.ph2_write(xb);
+            e.pair_store(xb);
             wave_sync();
-            // v = STFT(y_k - c y_{k-1}): normalise, scale by S; nothing to fetch or store
-            e.template ph3_update<false, 2>(a, t, xb);
+            // v = STFT(y_k - c y_{k-1}): normalise, scale by S, start the way back - on mirror
+            // pairs of bins; nothing to fetch or store
+            e.template ph3_pair<kNzh>(a, t, xb, xb);
+            wave_sync();
+            e.ph4_pair(xb, xb);
+            wave_sync();
+            e.ph5_read(xb);
+            wave_sync();
+            e.ph5_write(xb);
+            wave_sync();
+            e.ph6(a, t, xb);
+            wave_sync();
+            continue;
         } else if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
             wave_sync();
@@ -511,6 +524,8 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
     float* tile = sa + 32 * lds;               // [32][kMelTileStride] magnitudes of one half
     float* nyq = tile + 32 * kMelTileStride;   // [32] magnitudes of the Nyquist bin
     const int P = ea.L.P, F = ea.L.F;
+    constexpr int E = Geo<A>::E;
+    const int nzh = ea.L.s_pair_nzh;
     const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
     const int64_t row0 = (int64_t)blockIdx.x * 32;
     for (int i = threadIdx.x; i < 32 * Mp; i += 64 * kMelWaves) {
@@ -579,7 +594,10 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
                 float s4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s4[j] = trow[64 * (4 * g + j)];
-                reinterpret_cast<f4*>(snat)[(2 * h + g) * 64 + lane] = f4{s4[0], s4[1], s4[2], s4[3]};
+                // native order keeps all registers; pair order only a lane's own low registers
+                // (the first half of the registers), in the same place
+                if (!nzh || 8 * h + 4 * g < E / 2)
+                    reinterpret_cast<f4*>(snat)[(2 * h + g) * 64 + lane] = f4{s4[0], s4[1], s4[2], s4[3]};
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const int ka = 512 * h + low + 64 * (4 * g + 2 * pp);
@@ -596,6 +614,26 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
                 }
             }
             if (h == 0 && lane == 0) reinterpret_cast<f4*>(snat + P)[0] = f4{nyq[f], 0.f, 0.f, 0.f};
+            if (nzh && h == A - 1) {
+                // pair order: the magnitudes of the mirrors P - k of this lane's pairs i = NP - nzh
+                // .. NP - 1 (all in this half of the spectrum), and the self-mirrored bin P/2
+                const float* tr = tile + f * kMelTileStride;
+                auto mirror_of = [&](int i) -> float {
+                    if (low == 0) return i == 0 ? 0.f : tr[64 * (8 - i)];
+                    return tr[(64 - low) + 64 * (7 - i)];
+                };
+                float* hi = snat + (E / 2) * 64;
+                const int first = E / 2 - nzh;
+                if (nzh % 4 == 0) {
+                    for (int g = 0; g < nzh / 4; ++g)
+                        reinterpret_cast<f4*>(hi)[g * 64 + lane] =
+                            f4{mirror_of(first + 4 * g), mirror_of(first + 4 * g + 1), mirror_of(first + 4 * g + 2),
+                               mirror_of(first + 4 * g + 3)};
+                } else {
+                    reinterpret_cast<cf*>(hi)[lane] = cf{mirror_of(first), mirror_of(first + 1)};
+                }
+                if (lane == 0) snat[P + 1] = tr[A == 1 ? 256 : 0];
+            }
         }
         __syncthreads();
     }

@@ -100,6 +100,21 @@ __device__ __forceinline__ cf add_scaled_i(cf a, cf kk, cf u) {
         : "v"(u), "v"(kk), "v"(a));
     return r;
 }
+// the mirror images of the two: conj(k*a) - i*conj(u) and conj(a) + i*k*conj(u)
+__device__ __forceinline__ cf scale_subi_mirror(cf a, cf kk, cf u) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[1,0,1]"
+        : "=v"(r)
+        : "v"(a), "v"(kk), "v"(u));
+    return r;
+}
+__device__ __forceinline__ cf add_scaled_i_mirror(cf a, cf kk, cf u) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,0,1]"
+        : "=v"(r)
+        : "v"(u), "v"(kk), "v"(a));
+    return r;
+}
 #else
 GLV_HD cf addi(cf a, cf b) { return cf{a.x - b.y, a.y + b.x}; }
 GLV_HD cf subi(cf a, cf b) { return cf{a.x + b.y, a.y - b.x}; }
@@ -109,6 +124,8 @@ GLV_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * 
 GLV_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
 GLV_HD cf scale_subi(cf a, cf kk, cf u) { return cf{kk.x * a.x + u.y, kk.y * a.y - u.x}; }
 GLV_HD cf add_scaled_i(cf a, cf kk, cf u) { return cf{a.x - kk.x * u.y, a.y + kk.y * u.x}; }
+GLV_HD cf scale_subi_mirror(cf a, cf kk, cf u) { return cf{kk.x * a.x - u.y, -(kk.y * a.y) - u.x}; }
+GLV_HD cf add_scaled_i_mirror(cf a, cf kk, cf u) { return cf{a.x + kk.x * u.y, kk.y * u.x - a.y}; }
 #endif
 GLV_HD cf scale(cf a, float k) { return cf{a.x * k, a.y * k}; }
 // forward twiddles are stored as e^{-i*theta}; INV selects the conjugate
@@ -478,6 +495,64 @@ struct WaveFft {
             if (q == 0 && lane == 0) z = cf{a.x + a.y, a.x - a.y};
             v[q] = z;
         }
+    }
+
+    // ---- the split done on mirror PAIRS ----
+    // A bin k and its mirror P-k go through the same sums: with s = Zk + conj Zm, d = Zk - conj Zm,
+    // u = (0.5 W_N^k) d the two half-complex bins are X[k] = 0.5 s - i u and X[m] = conj(0.5 s) -
+    // i conj(u) (W_N^(P-k) = -conj W_N^k), and likewise on the way back.  So one lane of each
+    // mirror pair of lanes can do both bins: a lane keeps the LOW half of its registers (pair i =
+    // register i, bin k) and is sent the partner lane's register E-1-i (bin P-k), works on both,
+    // and sends the partner's result back.  Per frame that is one full exchange instead of two,
+    // six instead of ten operations per pair and direction, and half the twiddles.
+    // Lane 0 is its own partner (its mirrors are E-i, one row further down - the same offset
+    // trick as mirror_base); its bin 0 packs (DC, Nyquist) and its register E/2 holds the
+    // self-mirrored bin P/2, which the caller treats on its own.
+    static constexpr int NP = E / 2;  // pairs per lane
+    // exchange 1: every lane publishes its high registers
+    static GLV_HD void pair_store(const cf (&v)[E], cf* w, int lane) {
+#pragma unroll
+        for (int q = NP; q < E; ++q) w[(q - NP) * 64 + lane] = v[q];
+    }
+    // partners of pairs i0 .. i0+NQ-1 (register E-1-i of the partner lane)
+    template <int NQ>
+    static GLV_HD void pair_partners(cf (&m)[NQ], const cf* r, int mbase, int i0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) m[j] = r[(NP - 1 - (i0 + j)) * 64 + mbase];
+    }
+    // exchange 2: the partner's finished register goes back to where it will read it
+    static GLV_HD void pair_send(cf zm, cf* w, int mbase, int i) { w[(NP - 1 - i) * 64 + mbase] = zm; }
+    static GLV_HD void pair_receive(cf (&v)[E], const cf* r, int lane) {
+#pragma unroll
+        for (int q = NP; q < E; ++q) v[q] = r[(q - NP) * 64 + lane];
+    }
+    // forward: (a, b) = (Z[k], Z[P-k]) -> (X[k], X[P-k]); tw = 0.5 W_N^k
+    static GLV_HD void pair_fwd(cf a, cf b, cf tw, cf& xk, cf& xm) {
+        const cf half = cf{0.5f, 0.5f};
+        const cf s = add_conj(a, b), d = sub_conj(a, b);
+        const cf u = cmul(tw, d);
+        xk = scale_subi(s, half, u);
+        xm = scale_subi_mirror(s, half, u);
+    }
+    static GLV_HD cf pair_fwd_low(cf a, cf b, cf tw) {
+        const cf half = cf{0.5f, 0.5f};
+        const cf s = add_conj(a, b), d = sub_conj(a, b);
+        return scale_subi(s, half, cmul(tw, d));
+    }
+    // inverse: (a, b) = (X[k], X[P-k]) -> 2 (Z[k], Z[P-k])
+    static GLV_HD void pair_inv(cf a, cf b, cf tw, cf& zk, cf& zm) {
+        const cf two = cf{2.0f, 2.0f};
+        const cf s = add_conj(a, b), d = sub_conj(a, b);
+        const cf u = cmulc(d, tw);
+        zk = add_scaled_i(s, two, u);
+        zm = add_scaled_i_mirror(s, two, u);
+    }
+    // the same with X[P-k] = 0 (a bin whose target magnitude is zero)
+    static GLV_HD void pair_inv_low_only(cf a, cf tw, cf& zk, cf& zm) {
+        const cf two = cf{2.0f, 2.0f};
+        const cf u = cmulc(a, tw);
+        zk = add_scaled_i(a, two, u);
+        zm = add_scaled_i_mirror(a, two, u);
     }
 
     // ---- inverse (unnormalised) ----
