@@ -88,7 +88,7 @@ def main():
             rd, wr = 2 * f * 1024 / 1e6, w * 1024 / 1e6
             lines.append(f"| {k} | {f:.0f} | {w:.0f} | {rd:.2f} | {wr:.2f} | {rd + wr:.2f} |")
             # the iteration kernel: MODE_ITER_LIN (8) by default, MODE_ITER (0) with option linear = 0
-            if "gl_engine_kernel" in k and k.rstrip(">").endswith(("8, false", "0, false", "6, false", "4, false")):
+            if "gl_engine_kernel" in k and k.rstrip(">").endswith(("8, false", "9, false", "0, false", "6, false", "4, false")):
                 summary["gl_engine_iter_kernel"] = k
                 summary["gl_engine_iter_bytes_per_launch"] = int((rd + wr) * 1e6)
                 summary["gl_engine_iter_read_bytes"] = int(rd * 1e6)
