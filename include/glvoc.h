@@ -193,12 +193,14 @@ int glv_peak_scale(glv_plan* plan, float* y_dev, const int* n_samples_host, int 
  * librosa.stft / librosa.istft with the plan's n_fft, hop and window, exposed
  * for stage-wise checks of the two transforms inside librosa.griffinlim
  * (reference vocoder/mel_audio.py:126).
- *   glv_stft : y_dev (batch, y_stride), hop*(n_frames[b]-1) samples used per row
+ *   glv_stft : y_dev (batch, y_stride); row b holds n_samples_host[b] samples and gives
+ *              n_frames_host[b] = 1 + n_samples_host[b] / hop frames, as librosa frames a centred
+ *              signal of any length (n_samples_host NULL: hop*(n_frames[b]-1) samples per row)
  *              -> D_dev (batch, frames_stride, F) interleaved complex64.
- *   glv_istft: D_dev -> y_dev, same shapes.
+ *   glv_istft: D_dev -> y_dev (batch, y_stride), hop*(n_frames[b]-1) samples per row.
  */
 int glv_stft(glv_plan* plan, const float* y_dev, int64_t y_stride, const int* n_frames_host,
-             int batch, int frames_stride, float* D_dev, void* stream);
+             const int* n_samples_host, int batch, int frames_stride, float* D_dev, void* stream);
 int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int batch,
               int frames_stride, float* y_dev, int64_t y_stride, void* stream);
 
@@ -207,16 +209,16 @@ int glv_istft(glv_plan* plan, const float* D_dev, const int* n_frames_host, int 
  * (acoustic/dataset.py:75-84): librosa.feature.melspectrogram (|stft|^2 @ mel basis) and
  * librosa.power_to_db.  Same transform kernels as the vocoder; lets a wav -> mel -> wav round
  * trip stay on the device.
- *   glv_melspectrogram: y_dev (batch, y_stride) with hop*(n_frames[b]-1) samples per row ->
- *                       mel_dev (batch, frames_stride, n_mels) power values; needs
- *                       glv_plan_set_mel_basis.
+ *   glv_melspectrogram: y_dev (batch, y_stride), rows and frame counts as for glv_stft (signals of
+ *                       any length: the reference feeds whole utterances) -> mel_dev (batch,
+ *                       frames_stride, n_mels) power values; needs glv_plan_set_mel_basis.
  *   glv_power_to_db   : rows of n_valid_host[b] values -> 10*log10(max(amin, x)) -
  *                       10*log10(max(amin, ref)), ref = the row maximum (ref_is_max, i.e.
  *                       ref=np.max) or ref_value; then floored at (row maximum - top_db) unless
  *                       top_db < 0.  librosa defaults: amin 1e-10, top_db 80.
  */
 int glv_melspectrogram(glv_plan* plan, const float* y_dev, int64_t y_stride, const int* n_frames_host,
-                       int batch, int frames_stride, float* mel_dev, void* stream);
+                       const int* n_samples_host, int batch, int frames_stride, float* mel_dev, void* stream);
 int glv_power_to_db(glv_plan* plan, const float* x_dev, const int* n_valid_host, int batch,
                     int64_t stride, int ref_is_max, float ref_value, float amin, float top_db,
                     float* out_dev, void* stream);

@@ -500,6 +500,29 @@ def test_forward_mel_extraction_and_round_trip(voc, O, lj001):
         plan = voc.get_plan(n_fft, 256, n_fft, 80, 121, 1)
         mp = plan.melspectrogram(dev(y[None])).cpu().numpy()[0]
         assert rel_l2(mp, ms.T) < 1e-4
+    # A signal that is not a whole number of hops long, as the reference's preprocessing feeds it
+    # (whole utterances): librosa frames the zero-padded signal, so the last n_fft / (2 hop)
+    # frames still see the trailing samples, and ref=np.max / top_db act on the result
+    for extra in (1, 100, 255):
+        yl = np.concatenate([y, (3.0 * rng.standard_normal(extra)).astype(np.float32)])
+        got = voc.audio_to_mel_db(yl)
+        want = O.power_to_db(O.melspectrogram(yl, sr=22050, n_fft=2048, hop_length=256, win_length=2048, n_mels=80,
+                                              fmax=8000), ref=np.max).T
+        assert got.shape == want.shape == (121, 80)
+        assert np.max(np.abs(got - want)) < 2e-3
+        plan = voc.get_plan(2048, 256, 2048, 80, 121, 1)
+        d = plan.stft(dev(yl[None])).cpu().numpy()[0]
+        assert rel_l2(from_btf2(d), O.stft(yl, n_fft=2048, hop_length=256, win_length=2048)) < 2e-6
+    # rows of different lengths in one batch
+    plan = voc.get_plan(1024, 256, 1024, 80, 121, 2)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    yb = np.zeros((2, 256 * 120 + 77), np.float32)
+    yb[0], yb[1, :9000] = rng.standard_normal(yb.shape[1]), rng.standard_normal(9000)
+    mb = plan.melspectrogram(dev(yb), n_samples=[yb.shape[1], 9000]).cpu().numpy()
+    for row, n in ((0, yb.shape[1]), (1, 9000)):
+        ms = O.melspectrogram(yb[row, :n], sr=22050, n_fft=1024, hop_length=256, win_length=1024, n_mels=80, fmax=8000)
+        assert rel_l2(mb[row, :ms.shape[1]], ms.T) < 1e-4
+        assert np.all(mb[row, ms.shape[1]:] == 0)
     # Round trip mel -> wav -> mel.  (Through the reference's own function it would not close:
     # mel_audio.py feeds pinv(basis) @ POWER mel to Griffin-Lim as if it were a magnitude, so
     # the re-analysed dB range doubles.  librosa's mel_to_audio takes the square root and

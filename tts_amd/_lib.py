@@ -62,12 +62,12 @@ SIGNATURES = {
     "glv_shard_output_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                               ctypes.POINTER(ctypes.c_int64)]),
     "glv_shard_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "glv_melspectrogram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p,
+    "glv_melspectrogram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p, c_int_p,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_power_to_db": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
-    "glv_stft": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p,
+    "glv_stft": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p, c_int_p,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_istft": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

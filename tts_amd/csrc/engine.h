@@ -266,6 +266,7 @@ struct Engine {
     GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
         lane = lane_;
         run = r;
+        block_extra = a.raw_in ? 1 : 0;
         tab.twA = tables;
         tab.twB = tab.twA + G::TW_A;
         tab.twC = tab.twB + G::TW_B;
@@ -323,7 +324,10 @@ struct Engine {
             dst[i + HB * (A - 1)] = cf{q.z, q.w};
         }
     }
-    GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1; }
+    // the signal proper is blocks [R/2, R/2 + T-1); block_extra = 1 where the block after it holds
+    // the up to H-1 samples of a signal that is not a whole number of hops long (forward STFT)
+    int block_extra = 0;
+    GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1 + block_extra; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
         return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
     }

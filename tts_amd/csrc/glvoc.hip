@@ -1350,24 +1350,46 @@ extern "C" int glv_peak_normalize_noalloc(float* y_dev, const int* n_samples_dev
     return GLV_OK;
 }
 
-extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
-                        int batch, int frames_stride, float* D_dev, void* stream) {
-    if (!p || !y_dev || !D_dev) return fail(GLV_ERR_INVALID, "null argument");
-    DeviceGuard guard(p->device);
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// librosa.stft of every row into the plan's native spectrum buffer: run table, centred zero
+// padding (with the trailing partial hop of rows given by their sample counts), transform
+int forward_transform(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+                      const int* n_samples_host, int batch, int frames_stride, hipStream_t st) {
     int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
     if (rc != GLV_OK) return rc;
     int max_t = 0;
-    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
-    const int64_t max_len = (int64_t)p->hop * (max_t - 1);
-    if (y_stride < max_len) return fail(GLV_ERR_INVALID, "y_stride shorter than hop*(n_frames-1)");
+    for (int b = 0; b < batch; ++b) {
+        max_t = std::max(max_t, n_frames_host[b]);
+        const int64_t whole = (int64_t)p->hop * (n_frames_host[b] - 1);
+        const int64_t len = n_samples_host ? n_samples_host[b] : whole;
+        if (len < whole || len >= whole + p->hop)
+            return fail(GLV_ERR_INVALID, "n_samples[%d] = %lld does not give n_frames[%d] = %d frames "
+                        "(n_frames = 1 + n_samples / hop)", b, (long long)len, b, n_frames_host[b]);
+        if (len > y_stride) return fail(GLV_ERR_INVALID, "y_stride shorter than row %d", b);
+    }
+    if (n_samples_host)  // pageable source: staged before the call returns
+        HIP_TRY(hipMemcpyAsync(p->d_nsamples, n_samples_host, sizeof(int) * batch, hipMemcpyHostToDevice, st));
     const ElemArgs ea = elem_args(p, batch, frames_stride);
-    hipLaunchKernelGGL(pad_signal_kernel, dim3(grid_for(std::max<int64_t>(max_len, 1), 256), batch),
-                       dim3(256), 0, st, ea, y_dev, y_stride, p->d_ym[0]);
+    hipLaunchKernelGGL(pad_signal_kernel, dim3(grid_for((int64_t)p->hop * max_t, 256), batch), dim3(256), 0, st, ea,
+                       y_dev, y_stride, n_samples_host ? p->d_nsamples : (const int*)nullptr, p->d_ym[0]);
     IterArgs a = iter_args(p, frames_stride);
     a.raw_in = 1;
     set_io(p, a, 0, 1);
     HIP_TRY(p->launch_engine(MODE_STFT, false, a, engine_grid(p), st));
+    return GLV_OK;
+}
+
+}  // namespace
+
+extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
+                        const int* n_samples_host, int batch, int frames_stride, float* D_dev, void* stream) {
+    if (!p || !y_dev || !D_dev) return fail(GLV_ERR_INVALID, "null argument");
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = forward_transform(p, y_dev, y_stride, n_frames_host, n_samples_host, batch, frames_stride, st);
+    if (rc != GLV_OK) return rc;
+    const ElemArgs ea = elem_args(p, batch, frames_stride);
     p->launch_convert(false, ea, p->d_spec, 1.0f, reinterpret_cast<cf*>(D_dev), st);
     HIP_TRY(hipGetLastError());
     return GLV_OK;
@@ -1375,24 +1397,15 @@ extern "C" int glv_stft(glv_plan* p, const float* y_dev, int64_t y_stride, const
 
 
 extern "C" int glv_melspectrogram(glv_plan* p, const float* y_dev, int64_t y_stride, const int* n_frames_host,
-                                  int batch, int frames_stride, float* mel_dev, void* stream) {
+                                  const int* n_samples_host, int batch, int frames_stride, float* mel_dev,
+                                  void* stream) {
     if (!p || !y_dev || !mel_dev) return fail(GLV_ERR_INVALID, "null argument");
     if (!p->have_basis) return fail(GLV_ERR_STATE, "glv_plan_set_mel_basis has not been called");
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
-    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st);
+    int rc = forward_transform(p, y_dev, y_stride, n_frames_host, n_samples_host, batch, frames_stride, st);
     if (rc != GLV_OK) return rc;
-    int max_t = 0;
-    for (int b = 0; b < batch; ++b) max_t = std::max(max_t, n_frames_host[b]);
-    const int64_t max_len = (int64_t)p->hop * (max_t - 1);
-    if (y_stride < max_len) return fail(GLV_ERR_INVALID, "y_stride shorter than hop*(n_frames-1)");
     const ElemArgs ea = elem_args(p, batch, frames_stride);
-    hipLaunchKernelGGL(pad_signal_kernel, dim3(grid_for(std::max<int64_t>(max_len, 1), 256), batch),
-                       dim3(256), 0, st, ea, y_dev, y_stride, p->d_ym[0]);
-    IterArgs a = iter_args(p, frames_stride);
-    a.raw_in = 1;
-    set_io(p, a, 0, 1);
-    HIP_TRY(p->launch_engine(MODE_STFT, false, a, engine_grid(p), st));
     // |D|^2 in natural order (the S workspace is idle here), then mel = power @ basis^T
     p->launch_power(ea, p->d_spec, p->d_S, st);
     const int64_t rows = (int64_t)batch * frames_stride;

@@ -322,13 +322,17 @@ __global__ void spec_convert_kernel(ElemArgs ea, const cf* src, float inv_n, cf*
     }
 }
 
-// caller signal (B, y_stride) -> padded overlap-add coordinates, offset n_fft/2
-__global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride, float* ypad) {
+// caller signal (B, y_stride) -> padded overlap-add coordinates, offset n_fft/2.  Row b holds
+// n_samples[b] samples (or hop * (n_frames[b] - 1) without n_samples); the rest of the block after
+// the last whole hop is zero-filled, so that the transform sees the trailing partial hop.
+__global__ void pad_signal_kernel(ElemArgs ea, const float* y, int64_t y_stride, const int* n_samples,
+                                  float* ypad) {
     const int b = blockIdx.y;
-    const int64_t len = (int64_t)ea.L.hop * (ea.L.n_frames[b] - 1);
-    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < len;
+    const int64_t whole = (int64_t)ea.L.hop * (ea.L.n_frames[b] - 1);
+    const int64_t len = n_samples ? n_samples[b] : whole;
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < whole + ea.L.hop;
          n += (int64_t)gridDim.x * blockDim.x)
-        ypad[(int64_t)b * ea.L.y_utt_stride + ea.L.n_fft / 2 + n] = y[(int64_t)b * y_stride + n];
+        ypad[(int64_t)b * ea.L.y_utt_stride + ea.L.n_fft / 2 + n] = n < len ? y[(int64_t)b * y_stride + n] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float* y_main, const float* y_tail,

@@ -305,17 +305,28 @@ class GriffinLimPlan:
         _lib.check(self.lib.glv_shard_end(self._handle, _ptr(y), _stream_ptr(self.device)))
         return y[: int(n_count.value)], int(n_begin.value)
 
-    def melspectrogram(self, y, n_frames=None):
-        """(B, hop*(T-1)) -> (B, T, n_mels) mel power: librosa.feature.melspectrogram
-        (reference acoustic/dataset.py:75-83); set_mel_basis first."""
+    def _signal_rows(self, y, n_samples):
+        """Row lengths of a (B, stride) signal batch -> (n_samples, n_frames) int arrays with
+        librosa's frame count 1 + n_samples // hop for a centred signal."""
+        b, stride = y.shape
+        ns = np.full((b,), stride, np.int32) if n_samples is None else np.ascontiguousarray(n_samples, np.int32)
+        if ns.shape != (b,) or ns.min() < self.hop_length or ns.max() > stride:
+            raise ValueError(f"n_samples must be {b} values in [hop, {stride}]")
+        return ns, (1 + ns // self.hop_length).astype(np.int32)
+
+    def melspectrogram(self, y, n_samples=None):
+        """(B, stride) signals of n_samples[b] samples (default: the whole row) -> (B, T, n_mels) mel
+        power with T = 1 + stride // hop rows, 1 + n_samples[b] // hop of them used:
+        librosa.feature.melspectrogram (reference acoustic/dataset.py:75-83); set_mel_basis first."""
         self._check(y, (y.shape[-1],), "y")
         if self._basis_key is None:
             raise RuntimeError("set_mel_basis(sr, fmin, fmax) first")
         b, stride = y.shape
+        ns, nf = self._signal_rows(y, n_samples)
         t = stride // self.hop_length + 1
-        nf, nf_ptr = self._frames(n_frames, b, t)
         out = torch.zeros((b, t, self.n_mels), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.glv_melspectrogram(self._handle, _ptr(y), stride, nf_ptr, b, t, _ptr(out),
+        _lib.check(self.lib.glv_melspectrogram(self._handle, _ptr(y), stride, nf.ctypes.data_as(_lib.c_int_p),
+                                               ns.ctypes.data_as(_lib.c_int_p), b, t, _ptr(out),
                                                _stream_ptr(self.device)))
         return out
 
@@ -337,14 +348,16 @@ class GriffinLimPlan:
                                             _stream_ptr(self.device)))
         return out.reshape(x.shape)
 
-    def stft(self, y, n_frames=None):
-        """(B, hop*(T-1)) -> (B, T, F, 2); librosa.stft(center=True, pad_mode='constant')."""
+    def stft(self, y, n_samples=None):
+        """(B, stride) signals of n_samples[b] samples (default: the whole row) -> (B, T, F, 2) with
+        T = 1 + stride // hop; librosa.stft(center=True, pad_mode='constant')."""
         self._check(y, (y.shape[-1],), "y")
         b, stride = y.shape
+        ns, nf = self._signal_rows(y, n_samples)
         t = stride // self.hop_length + 1
-        nf, nf_ptr = self._frames(n_frames, b, t)
         out = torch.zeros((b, t, self.n_bins, 2), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.glv_stft(self._handle, _ptr(y), stride, nf_ptr, b, t, _ptr(out),
+        _lib.check(self.lib.glv_stft(self._handle, _ptr(y), stride, nf.ctypes.data_as(_lib.c_int_p),
+                                     ns.ctypes.data_as(_lib.c_int_p), b, t, _ptr(out),
                                      _stream_ptr(self.device)))
         return out
 
@@ -562,9 +575,7 @@ def audio_to_mel_db(y, sr=22050, n_fft=2048, hop_length=256, win_length=2048, n_
     """The reference's mel extraction (acoustic/dataset.py:75-84):
     ``librosa.power_to_db(librosa.feature.melspectrogram(y=y, sr=sr, n_mels=80, fmax=8000,
     n_fft=2048, hop_length=256, win_length=2048), ref=np.max).T`` -> (T, n_mels) dB in
-    [-80, 0].  The signal is cut to a whole number of hops (T = 1 + len(y) // hop_length
-    frames, as librosa frames it; the up to hop_length-1 trailing samples librosa's last
-    frames would still see are dropped)."""
+    [-80, 0], T = 1 + len(y) // hop_length frames over the whole signal, as librosa frames it."""
     sig = y.detach() if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
     if sig.dim() != 1:
         raise ValueError("y must be 1-D")
@@ -573,7 +584,7 @@ def audio_to_mel_db(y, sr=22050, n_fft=2048, hop_length=256, win_length=2048, n_
         raise ValueError("signal shorter than one hop")
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, 0.0, fmax)
-    sig = sig[: hop_length * (frames - 1)].to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
+    sig = sig.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
     mel = plan.melspectrogram(sig)
     db = plan.power_to_db(mel)[0]
     return db if return_tensor else db.cpu().numpy()
