@@ -244,6 +244,12 @@ int glv_power_to_db(glv_plan* plan, const float* x_dev, const int* n_valid_host,
  *   from `seed` per global frame index, so the result does not depend on the sharding.
  *   glv_shard_end writes this shard's n_count samples, which start at sample n_begin of the
  *   whole waveform (glv_shard_output_range), un-normalised.
+ *   glv_shard_halo_views is the swap without copies: it returns where, inside the plan's
+ *   workspace, the halos of the NEWEST generation lie - two regions to send from and two to
+ *   receive into, glv_shard_halo_samples() floats each (NULL on the side without a neighbour).
+ *   A transport that takes device pointers (RCCL send / recv) moves them in place, ordered on the
+ *   stream after glv_shard_begin / glv_shard_step and before the next step; the pointers change
+ *   with every step (three generations rotate) and are valid until glv_shard_end.
  * A shard needs at least 2*(n_fft/hop - 1) frames.  One shard per plan at a time.
  */
 int glv_shard_begin(glv_plan* plan, const float* S_dev, const float* phase0_dev, uint64_t seed,
@@ -253,6 +259,8 @@ int glv_shard_halo_samples(const glv_plan* plan);
 int glv_shard_halo_pack(glv_plan* plan, float* to_prev_dev, float* to_next_dev, void* stream);
 int glv_shard_halo_unpack(glv_plan* plan, const float* from_prev_dev, const float* from_next_dev,
                           void* stream);
+int glv_shard_halo_views(glv_plan* plan, float** send_prev, float** send_next, float** recv_prev,
+                         float** recv_next);
 int glv_shard_output_range(const glv_plan* plan, int64_t* n_begin, int64_t* n_count);
 int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
                                            ctypes.c_void_p]),
     "glv_shard_halo_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p]),
+    "glv_shard_halo_views": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
     "glv_shard_output_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                               ctypes.POINTER(ctypes.c_int64)]),
     "glv_shard_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -1203,6 +1203,23 @@ extern "C" int glv_shard_halo_unpack(glv_plan* p, const float* from_prev_dev, co
     return GLV_OK;
 }
 
+extern "C" int glv_shard_halo_views(glv_plan* p, float** send_prev, float** send_next, float** recv_prev,
+                                    float** recv_next) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (!send_prev || !send_next || !recv_prev || !recv_next) return fail(GLV_ERR_INVALID, "null argument");
+    // The halos are contiguous pieces of the newest overlap-add generation: this shard's head
+    // blocks [t0, t0+R-1) and tail blocks [t1, t1+R-1) go out, the neighbours' tails and heads
+    // of the same blocks come in beside them.
+    const int cur = p->shard_cur;
+    const int64_t end = (int64_t)(p->shard_t1 - p->shard_t0) * p->hop;
+    *send_prev = p->shard_t0 > 0 ? p->d_ym[cur] : nullptr;
+    *recv_prev = p->shard_t0 > 0 ? p->d_yt[cur] : nullptr;
+    *send_next = p->shard_t1 < p->shard_T ? p->d_yt[cur] + end : nullptr;
+    *recv_next = p->shard_t1 < p->shard_T ? p->d_ym[cur] + end : nullptr;
+    return GLV_OK;
+}
+
 extern "C" int glv_shard_output_range(const glv_plan* p, int64_t* n_begin, int64_t* n_count) {
     int rc = shard_check(p);
     if (rc != GLV_OK) return rc;

@@ -120,10 +120,17 @@ def exchange_halos(to_prev, to_next, from_prev, from_next, *, group=None):
     first rank has no previous, the last no next neighbour).  Tensors are the
     (n_fft - hop)-sample overlap-add partial sums at the two shard boundaries."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    # a transport that only moves host memory (gloo) gets host copies of device tensors
-    staged = dist.get_backend(group) != "nccl" and to_prev.is_cuda
-    send_prev, send_next = (to_prev.cpu(), to_next.cpu()) if staged else (to_prev, to_next)
-    recv_prev, recv_next = (torch.empty_like(send_prev), torch.empty_like(send_next)) if staged else (from_prev, from_next)
+    # a transport that only moves host memory (gloo) gets host copies of device tensors; a side
+    # without a neighbour may be None
+    tensors = [t for t in (to_prev, to_next, from_prev, from_next) if t is not None]
+    staged = dist.get_backend(group) != "nccl" and bool(tensors) and tensors[0].is_cuda
+
+    def host(t):
+        return t.cpu() if (staged and t is not None) else t
+
+    send_prev, send_next = host(to_prev), host(to_next)
+    recv_prev = torch.empty_like(send_prev) if (staged and rank > 0) else from_prev
+    recv_next = torch.empty_like(send_next) if (staged and rank < world - 1) else from_next
     ops = []
     if rank > 0:
         ops.append(dist.P2POp(dist.isend, send_prev, rank - 1, group))
@@ -132,6 +139,8 @@ def exchange_halos(to_prev, to_next, from_prev, from_next, *, group=None):
         ops.append(dist.P2POp(dist.isend, send_next, rank + 1, group))
         ops.append(dist.P2POp(dist.irecv, recv_next, rank + 1, group))
     if ops:
+        # under RCCL wait() only makes the current stream wait for the communicator's stream:
+        # the host does not block, and the next step is enqueued behind the transfer
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     if staged:
@@ -179,13 +188,17 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
     s_local = plan.mel_invert(local.unsqueeze(0), float(mean), float(std))[0]
     plan.shard_begin(s_local, t0, frames, seed=seed)
 
+    on_device = dist.get_backend(group) == "nccl"
+
     def swap():
-        to_prev, to_next = plan.shard_halo_pack()
-        from_prev, from_next = plan.shard_halo_buffers()
-        if dist.get_backend(group) != "nccl":
-            torch.cuda.current_stream(plan.device).synchronize()  # RCCL orders itself after the stream
+        # The halos are sent from and received into the plan's workspace where they lie: no
+        # packing.  Under RCCL the transfers are ordered on the device after the step that wrote
+        # them and before the step that reads them (wait() makes the compute stream wait for the
+        # communicator's, not the host); a host-memory transport has to drain the stream first.
+        to_prev, to_next, from_prev, from_next = plan.shard_halo_views()
+        if not on_device:
+            torch.cuda.current_stream(plan.device).synchronize()
         exchange_halos(to_prev, to_next, from_prev, from_next, group=group)
-        plan.shard_halo_unpack(from_prev, from_next)
 
     swap()
     for _ in range(n_iter):

@@ -39,6 +39,13 @@ def _int_array(values):
     return arr, arr.ctypes.data_as(_lib.c_int_p)
 
 
+class _DeviceFloats:
+    """n float32 values at a raw device address, presented through the array interface torch reads."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
 class GriffinLimPlan:
     """Owns one ``glv_plan``: tables and device workspace for a fixed
     (n_fft, hop_length, win_length, n_mels) and capacity (max_frames, max_batch).
@@ -295,6 +302,24 @@ class GriffinLimPlan:
         from_next = self._halo[3] if from_next is None else from_next
         _lib.check(self.lib.glv_shard_halo_unpack(self._handle, _ptr(from_prev), _ptr(from_next),
                                                   _stream_ptr(self.device)))
+
+    def shard_halo_views(self):
+        """(send_prev, send_next, recv_prev, recv_next): float32 tensors that ALIAS the halo regions
+        of the newest generation inside the plan's workspace (None on the side without a
+        neighbour) - what a device-pointer transport sends from and receives into, no copies."""
+        ptrs = [ctypes.c_void_p() for _ in range(4)]
+        _lib.check(self.lib.glv_shard_halo_views(self._handle, *[ctypes.byref(p) for p in ptrs]))
+        n = int(self.lib.glv_shard_halo_samples(self._handle))
+        cache = self.__dict__.setdefault("_views", {})
+        out = []
+        for p in ptrs:
+            if not p.value:
+                out.append(None)
+                continue
+            if p.value not in cache:
+                cache[p.value] = torch.as_tensor(_DeviceFloats(p.value, n), device=self.device)
+            out.append(cache[p.value])
+        return tuple(out)
 
     def shard_end(self):
         """Returns (y_local, n_begin): this shard's samples [n_begin, n_begin + len(y_local))
