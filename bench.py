@@ -383,9 +383,12 @@ def main():
         }
         if nnls:
             result["nnls"] = {"ms_per_solve": round(float(np.mean(nnls_ms)), 4), "steps": args.nnls_steps,
-                              "flop_per_solve": 4 * args.nnls_steps * batch * t_max * f_bins * N_MELS,
-                              "tflops": round(4 * args.nnls_steps * batch * t_max * f_bins * N_MELS
-                                              / (float(np.mean(nnls_ms)) * 1e-3) / 1e12, 2)}
+                              # flops of the two dense products per step; the solver skips the all-zero
+                              # blocks of the banded mel basis, so it executes about a quarter of them
+                              # (executed MFMA work and busy cycles: profiles/*_nnls_pmc_counters.json)
+                              "dense_flop_per_solve": 4 * args.nnls_steps * batch * t_max * f_bins * N_MELS,
+                              "dense_equivalent_tflops": round(4 * args.nnls_steps * batch * t_max * f_bins * N_MELS
+                                                               / (float(np.mean(nnls_ms)) * 1e-3) / 1e12, 2)}
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(mel_host, frames_list, MEAN, STD, min(args.cpu_utts, batch))
         print(json.dumps(result), flush=True)

@@ -114,16 +114,18 @@ int glv_mel_invert(glv_plan* plan, const float* mel_db_dev, int batch, int frame
  * that the reference's older scripts call (test_cnn_model.py:117-119, test_1.py:52-54,
  * z_AR/test_AR_model.py:12-14):
  *     X = argmin_{X >= 0} 0.5 * || basis @ X - mel ||^2 ,  S = X ** (1 / power)
- * started from librosa's X0 = max(pinv @ mel, 0) and advanced by n_steps projected-gradient
- * steps X <- max(X - step * basis^T (basis X - mel), 0) (librosa runs L-BFGS-B from the same
- * start; F > n_mels, so the minimiser is not unique and only the mel-domain residual is
- * comparable between solvers).  step should be 1 / ||basis||_2^2.
+ * started from librosa's X0 = max(pinv @ mel, 0) and advanced by at most n_steps
+ * projected-gradient steps X <- max(X - step * basis^T (basis X - mel), 0) (librosa runs
+ * L-BFGS-B from the same start; F > n_mels, so the minimiser is not unique and only the
+ * mel-domain residual is comparable between solvers).  step should be 1 / ||basis||_2^2.
+ * A frame stops moving once its residual ||basis X - mel|| <= tol * ||mel|| (tol = 0: every
+ * frame takes all n_steps steps); frames do not influence each other.
  *   glv_plan_set_mel_basis: (n_mels, F) row-major float32 librosa.filters.mel matrix.
  *   mel_dev: (batch, frames_stride, n_mels) mel POWER values (not dB); S_dev as glv_mel_invert.
  */
 int glv_plan_set_mel_basis(glv_plan* plan, const float* basis_MxF_host);
 int glv_mel_invert_nnls(glv_plan* plan, const float* mel_dev, int batch, int frames_stride,
-                        int n_steps, float step, float power, float* S_dev, void* stream);
+                        int n_steps, float step, float tol, float power, float* S_dev, void* stream);
 
 /*
  * librosa.griffinlim(S, n_iter, hop_length, win_length, momentum, init='random')
@@ -283,6 +285,10 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
  *                        "alias_utts" (0/1: measurement aid - every utterance of the batch uses the first
  *                        one's state, so the loop runs out of cache: compute-only time; output is
  *                        garbage),
+ *                        "zero_skip" (1/0, default 1: the iteration leaves out the bins whose rows of the
+ *                        inverse basis are all zero - their magnitudes are exactly zero),
+ *                        "nnls_fused" (1/0, default 1: all steps of glv_mel_invert_nnls in one launch
+ *                        with the solution resident in registers; 0 = two launches per step),
  *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue
  *                        their loads and stores but skip the arithmetic; output is garbage).
  *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration

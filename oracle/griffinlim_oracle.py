@@ -319,8 +319,9 @@ def nnls_init(a, b):
     return x
 
 
-def nnls_projected_gradient(a, b, n_steps=200, x0=None):
-    """Projected gradient on 0.5*||A X - B||^2 s.t. X >= 0, step 1/||A||_2^2.
+def nnls_projected_gradient(a, b, n_steps=200, x0=None, tol=0.0):
+    """Projected gradient on 0.5*||A X - B||^2 s.t. X >= 0, step 1/||A||_2^2.  With ``tol`` a
+    frame (column) stops moving once ||A x - b|| <= tol * ||b||.
 
     librosa.util.nnls minimises the same objective with L-BFGS-B from the same
     start; the problem is under-determined (F >> n_mels), so the minimiser is
@@ -331,8 +332,13 @@ def nnls_projected_gradient(a, b, n_steps=200, x0=None):
     x = nnls_init(a, b) if x0 is None else np.array(x0, copy=True)
     step = a.dtype.type(1.0 / (np.linalg.norm(a.astype(np.float64), 2) ** 2))
     for _ in range(n_steps):
-        grad = a.T @ (a @ x - b)
-        x = np.maximum(x - step * grad, 0)
+        r = a @ x - b
+        if tol > 0:
+            active = np.linalg.norm(r, axis=0) > tol * np.linalg.norm(b, axis=0)
+            if not active.any():
+                break
+            r = r * active
+        x = np.maximum(x - step * (a.T @ r), 0)
     return x
 
 

@@ -462,6 +462,20 @@ def test_nnls_inversion(voc, O, n_fft, n_mels):
     # power = 2 takes the square root (magnitude from power)
     s = plan.mel_invert_nnls(md, n_steps=100, power=2.0).cpu().numpy()[0].T
     assert rel_l2(s, np.sqrt(want)) < 1e-4
+    # all steps in one launch (the default) and one product per launch are the same iteration
+    plan.set_option("nnls_fused", 0)
+    x_unfused = plan.mel_invert_nnls(md, n_steps=100, power=1.0).cpu().numpy()[0].T
+    plan.set_option("nnls_fused", 1)
+    assert rel_l2(x, x_unfused) < 1e-5
+    # frames stop on their own residual: same result as the oracle's rule, residual at the bound
+    # for the frames that stopped, and frames do not influence each other
+    xt = plan.mel_invert_nnls(md, n_steps=400, power=1.0, tol=0.02).cpu().numpy()[0].T
+    want_t = O.nnls_projected_gradient(basis, m, n_steps=400, tol=0.02)
+    assert rel_l2(xt, want_t) < 1e-3
+    rel = np.linalg.norm(basis @ xt - m, axis=0) / np.linalg.norm(m, axis=0)
+    assert np.all(rel < 0.021) and np.all(xt >= 0)
+    sub = plan.mel_invert_nnls(dev(np.ascontiguousarray(m.T[None, 7:19])), n_steps=400, power=1.0, tol=0.02)
+    assert np.array_equal(sub.cpu().numpy()[0].T, xt[:, 7:19])
     plan.close()
     # the secondary entry point end to end, librosa defaults (hop = n_fft/4, no peak normalisation)
     y = voc.mel_to_audio(m, sr=sr, n_fft=n_fft, n_iter=4, n_steps=50, init_phase=5)

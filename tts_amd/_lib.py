@@ -33,8 +33,8 @@ SIGNATURES = {
                                       ctypes.c_void_p]),
     "glv_plan_set_mel_basis": (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
     "glv_mel_invert_nnls": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
-                                           ctypes.c_void_p]),
+                                           ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
     "glv_griffinlim": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_uint64, c_int_p, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64,

@@ -85,6 +85,15 @@ struct glv_plan {
     float* d_basis_t = nullptr;  // (F, n_mels)
     float* d_resid = nullptr;    // (rows, n_mels) residual A X - B
     bool have_basis = false;
+    // tables of the fused NNLS kernel (nnls_fused_kernel): the basis as MFMA operand streams of
+    // the two products, and the mel range every 32-bin tile touches
+    float* d_nnls_a1 = nullptr;
+    float* d_nnls_a2 = nullptr;
+    int* d_nnls_lo = nullptr;
+    int* d_nnls_hi = nullptr;
+    int nnls_mt = 0, nnls_ct = 0;  // mel tiles (0: shape not covered, unfused steps), bin tiles
+    int nnls_fused = 1;            // option: 0 = one product per launch (the unfused form)
+    int64_t nnls_mfma_per_block_step = 0;
     // device workspace
     cf* d_spec = nullptr;
     float* d_S = nullptr;
@@ -303,7 +312,7 @@ void plan_free(glv_plan* p) {
     drop_graphs(p);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_nnls_a1, p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial, p->d_utt_ids};
     for (void* q : dev)
@@ -635,6 +644,8 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     } else if (!strcmp(name, "linear")) {
         p->linear = value != 0;
         drop_graphs(p);
+    } else if (!strcmp(name, "nnls_fused")) {
+        p->nnls_fused = value != 0;
     } else if (!strcmp(name, "zero_skip")) {
         p->zero_skip = value != 0;
     } else if (!strcmp(name, "single_frame")) {
@@ -746,19 +757,97 @@ extern "C" int glv_plan_set_mel_basis(glv_plan* p, const float* basis_host) {
         for (int f = 0; f < p->F; ++f) t[(size_t)f * p->n_mels + m] = basis_host[(size_t)m * p->F + f];
     HIP_TRY(hipMemcpy(p->d_basis, basis_host, sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->d_basis_t, t.data(), sizeof(float) * p->F * p->n_mels, hipMemcpyHostToDevice));
+    {
+        // operand streams of the fused solver, see nnls_fused_kernel
+        const int M = p->n_mels, F = p->F, MT = (M + 31) / 32, CT = (F + 31) / 32, MP = 32 * MT;
+        p->nnls_mt = MT <= 4 ? MT : 0;
+        p->nnls_ct = CT;
+        if (p->nnls_mt) {
+            auto at = [&](int m, int f) -> float { return (m < M && f < F) ? basis_host[(size_t)m * F + f] : 0.f; };
+            std::vector<float> a1((size_t)CT * MT * 16 * 64), a2((size_t)CT * (MP / 2) * 64);
+            std::vector<int> lo(CT, 0), hi(CT, 0);
+            int64_t mfma = 0;
+            for (int c = 0; c < CT; ++c) {
+                int l = MP, h = 0;
+                for (int m = 0; m < M; ++m)
+                    for (int f = 32 * c; f < std::min(F, 32 * c + 32); ++f)
+                        if (basis_host[(size_t)m * F + f] != 0.f) {
+                            l = std::min(l, m);
+                            h = std::max(h, m + 1);
+                        }
+                if (h > l) {
+                    lo[c] = l;
+                    hi[c] = h;
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (!(h <= 32 * mt || l >= 32 * (mt + 1))) mfma += 16;
+                    mfma += (((h + 1) >> 1) - ((l >> 1) & ~3) + 3) / 4 * 4;
+                }
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 5, i = lane & 31;
+                    for (int mt = 0; mt < MT; ++mt)
+                        for (int s2 = 0; s2 < 16; ++s2)
+                            a1[(((size_t)c * MT + mt) * 16 + s2) * 64 + lane] =
+                                at(32 * mt + i, 32 * c + (s2 & 3) + 8 * (s2 >> 2) + 4 * g);
+                    for (int j = 0; j < MP / 2; ++j) a2[((size_t)c * (MP / 2) + j) * 64 + lane] = at(2 * j + g, 32 * c + i);
+                }
+            }
+            p->nnls_mfma_per_block_step = mfma;
+            for (void* q : {(void*)p->d_nnls_a1, (void*)p->d_nnls_a2, (void*)p->d_nnls_lo, (void*)p->d_nnls_hi})
+                if (q) (void)hipFree(q);
+            p->d_nnls_a1 = p->d_nnls_a2 = nullptr;
+            p->d_nnls_lo = p->d_nnls_hi = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_a1), a1.size() * sizeof(float)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_a2), a2.size() * sizeof(float)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_lo), CT * sizeof(int)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_hi), CT * sizeof(int)));
+            HIP_TRY(hipMemcpy(p->d_nnls_a1, a1.data(), a1.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_nnls_a2, a2.data(), a2.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_nnls_lo, lo.data(), CT * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_nnls_hi, hi.data(), CT * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     p->have_basis = true;
     return GLV_OK;
 }
 
+namespace {
+
+template <int NW, int TPW>
+hipError_t launch_nnls_fused(const glv_plan* p, float* X, const float* B, int64_t rows, int n_steps, float step,
+                             float tol, hipStream_t st) {
+    const int MP = 32 * p->nnls_mt;
+    const size_t lds = ((size_t)(NW + 1) * MP * 32 + 64) * sizeof(float);
+    const dim3 grid((unsigned)((rows + 31) / 32)), block(64 * NW);
+#define GLV_NNLS_CASE(MT_)                                                                                      \
+    case MT_:                                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnls_fused_kernel<NW, TPW, MT_>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        hipLaunchKernelGGL((nnls_fused_kernel<NW, TPW, MT_>), grid, block, lds, st, X, B, p->d_nnls_a1,         \
+                           p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, rows, p->F, p->n_mels, p->nnls_ct, n_steps, \
+                           step, tol);                                                                          \
+        break;
+    switch (p->nnls_mt) {
+        GLV_NNLS_CASE(1)
+        GLV_NNLS_CASE(2)
+        GLV_NNLS_CASE(3)
+        GLV_NNLS_CASE(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef GLV_NNLS_CASE
+    return hipGetLastError();
+}
+
+}  // namespace
+
 extern "C" int glv_mel_invert_nnls(glv_plan* p, const float* mel_dev, int batch, int frames_stride,
-                                   int n_steps, float step, float power, float* S_dev, void* stream) {
+                                   int n_steps, float step, float tol, float power, float* S_dev, void* stream) {
     if (!p || !mel_dev || !S_dev) return fail(GLV_ERR_INVALID, "null argument");
     if (!p->have_pinv || !p->have_basis)
         return fail(GLV_ERR_STATE, "glv_plan_set_inverse_basis and glv_plan_set_mel_basis must be called first");
     if (batch < 1 || frames_stride < 1 || (int64_t)batch * frames_stride > (int64_t)p->max_batch * p->max_frames)
         return fail(GLV_ERR_INVALID, "batch x frames_stride exceeds the plan's capacity");
-    if (n_steps < 0 || !(step > 0.f) || !(power > 0.f))
-        return fail(GLV_ERR_INVALID, "n_steps >= 0, step > 0 and power > 0 are required");
+    if (n_steps < 0 || !(step > 0.f) || !(power > 0.f) || !(tol >= 0.f))
+        return fail(GLV_ERR_INVALID, "n_steps >= 0, step > 0, tol >= 0 and power > 0 are required");
     DeviceGuard guard(p->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)batch * frames_stride;
@@ -768,12 +857,22 @@ extern "C" int glv_mel_invert_nnls(glv_plan* p, const float* mel_dev, int batch,
     // X0 = max(pinv @ B, 0): the deterministic start of librosa.util.nnls
     hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_CLAMP>), grid_f, dim3(256), 0, st, mel_dev, p->d_pinv, rows, M, F,
                        0.f, 0.f, 0.f, (const float*)nullptr, S_dev);
-    for (int i = 0; i < n_steps; ++i) {
-        // R = X A^T - B   (rows x M), then X = max(X - step * R A, 0)
-        hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_SUB>), grid_m, dim3(256), 0, st, S_dev, p->d_basis, rows, F, M,
-                           0.f, 0.f, 0.f, mel_dev, p->d_resid);
-        hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_STEP>), grid_f, dim3(256), 0, st, p->d_resid, p->d_basis_t, rows,
-                           M, F, 0.f, 0.f, step, S_dev, S_dev);
+    if (p->nnls_fused && p->nnls_mt && n_steps > 0) {
+        // all steps in one launch, X resident in registers (nnls_fused_kernel)
+        if (p->nnls_ct <= 20)
+            HIP_TRY((launch_nnls_fused<4, 5>(p, S_dev, mel_dev, rows, n_steps, step, tol, st)));
+        else if (p->nnls_ct <= 40)
+            HIP_TRY((launch_nnls_fused<8, 5>(p, S_dev, mel_dev, rows, n_steps, step, tol, st)));
+        else
+            return fail(GLV_ERR_UNSUPPORTED, "n_fft too large for the fused solver");
+    } else {
+        for (int i = 0; i < n_steps; ++i) {
+            // R = X A^T - B   (rows x M), then X = max(X - step * R A, 0)
+            hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_SUB>), grid_m, dim3(256), 0, st, S_dev, p->d_basis, rows, F,
+                               M, 0.f, 0.f, 0.f, mel_dev, p->d_resid);
+            hipLaunchKernelGGL((gemm_nt_kernel<false, EPI_STEP>), grid_f, dim3(256), 0, st, p->d_resid, p->d_basis_t,
+                               rows, M, F, 0.f, 0.f, step, S_dev, S_dev);
+        }
     }
     if (power != 1.0f)
         hipLaunchKernelGGL(root_kernel, dim3(grid_for(rows * F, 256)), dim3(256), 0, st, S_dev, rows * F,

@@ -501,6 +501,173 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Non-negative least squares, all projected-gradient steps in ONE kernel.
+//   X <- max(X - step * (X A^T - B) A, 0)      X: (rows, F) >= 0,  A: (M, F) mel basis,  B: (rows, M)
+// A block takes 32 rows and keeps its X tile in REGISTERS for the whole solve, transposed and in
+// the accumulator layout of v_mfma_f32_32x32x2_f32: wave w owns the 32-bin column tiles c = w,
+// w + NW, ..., and X^T tile c is 16 registers per lane (bin 32c + (reg & 3) + 8 (reg >> 2) + 4 g,
+// row l % 32; g = lane / 32).  Both products of a step then run on the matrix cores without
+// moving X:
+//   phase 1   R^T (M x 32)  = A (M x F) . X^T (F x 32): the accumulator registers of X^T ARE the
+//             B operands (register s of lane group g is bin b0(s) + 4 g of the tile: the k-pairs
+//             of the product are taken as (b0, b0 + 4), which the host-built A1 table matches);
+//             every wave sums over its own bins, the partial R^T of the NW waves meet in LDS,
+//             B is subtracted there;
+//   phase 2   X^T tile -= step * A^T tile (32 x M) . R^T (M x 32): R^T from LDS, A2 table from L2.
+// The mel basis is banded (a bin tile meets only a few mel filters), so each tile carries the
+// range of mels it touches and both phases skip the all-zero blocks: the same sums, a quarter
+// of the matrix instructions.  Rows stop on their own once ||X A^T - B|| <= tol ||B||.
+//   A1[c][mt][s][lane] = A[32 mt + l % 32][32 c + b0(s) + 4 g]        (0 outside the matrix)
+//   A2[c][j][lane]     = A[2 j + g][32 c + l % 32]
+//   mel_lo / mel_hi[c]   mels [lo, hi) with a non-zero entry in bin tile c
+// X0 (rows, F) in, X (rows, F) out, in place.
+template <int NW, int TPW, int MT>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(float* __restrict__ X, const float* __restrict__ Bmel,
+                                                           const float* __restrict__ A1, const float* __restrict__ A2,
+                                                           const int* __restrict__ mel_lo, const int* __restrict__ mel_hi,
+                                                           int64_t rows, int F, int M, int CT, int n_steps, float step,
+                                                           float tol) {
+    constexpr int MP = 32 * MT;  // mels, padded to whole tiles
+    extern __shared__ float nnls_smem[];
+    float* part = nnls_smem;                 // [NW][MP][32] partial R^T of every wave
+    float* Rl = part + NW * MP * 32;         // [MP][32] R^T = X A^T - B
+    float* bnorm = Rl + MP * 32;             // [32] ||B||^2 per row
+    float* rowstep = bnorm + 32;             // [32] step of every row, 0 once it has converged
+    // "some row still moves", one flag per iteration modulo 3: the flag of iteration it + 1 is
+    // cleared at the top of iteration it, two block-wide barriers after its last reader
+    __shared__ int any_active[3];
+    if (threadIdx.x < 3) any_active[threadIdx.x] = 0;
+    // (wave-uniform values forced into scalar registers: the tile ranges steer branches)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 5,
+              i = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const bool row_ok = row0 + i < rows;
+    // B^T, the entries this thread subtracts in the reduction of every step
+    constexpr int EPT = MP * 32 / (64 * NW);
+    float bt[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = threadIdx.x + q * 64 * NW, m = e >> 5, n = e & 31;
+        bt[q] = (m < M && row0 + n < rows) ? Bmel[(row0 + n) * M + m] : 0.f;
+    }
+    if (threadIdx.x < 32) {
+        float b2 = 0.f;
+        if (row0 + threadIdx.x < rows)
+            for (int m = 0; m < M; ++m) {
+                const float bv = Bmel[(row0 + threadIdx.x) * M + m];
+                b2 += bv * bv;
+            }
+        bnorm[threadIdx.x] = b2;
+        rowstep[threadIdx.x] = step;
+    }
+    // this wave's tiles of X^T
+    f32x16 xt[TPW];
+    int lo[TPW], hi[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int c = wave + NW * t;
+        lo[t] = __builtin_amdgcn_readfirstlane(c < CT ? mel_lo[c] : 0);
+        hi[t] = __builtin_amdgcn_readfirstlane(c < CT ? mel_hi[c] : 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int bin = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
+            xt[t][r] = (row_ok && bin < F) ? X[(row0 + i) * F + bin] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < n_steps; ++it) {
+        // ---- phase 1: this wave's share of R^T ----
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int c = wave + NW * t;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (hi[t] <= 32 * mt || lo[t] >= 32 * (mt + 1)) continue;  // no filter of this tile there
+                const float* a1 = A1 + ((int64_t)(c * MT + mt) * 16) * 64 + lane;
+                float av[16];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) av[s2] = a1[s2 * 64];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], xt[t][s2], acc[mt], 0, 0, 0);
+                // one block's operands at a time: the compiler would otherwise fetch those of all
+                // TPW * MT blocks ahead and run out of registers
+                GLV_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                part[((wave * MP) + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g) * 32 + i] = acc[mt][r];
+        if (threadIdx.x == 0) any_active[(it + 1) % 3] = 0;
+        __syncthreads();
+        // ---- R^T = sum of the partials - B^T, in a fixed order ----
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = threadIdx.x + q * 64 * NW;
+            float r = part[e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) r += part[w * MP * 32 + e];
+            Rl[e] = r - bt[q];
+        }
+        __syncthreads();
+        if (tol > 0.f && threadIdx.x < 32) {
+            float r2 = 0.f;
+            for (int m = 0; m < M; ++m) r2 += Rl[m * 32 + threadIdx.x] * Rl[m * 32 + threadIdx.x];
+            const bool active = r2 > tol * tol * bnorm[threadIdx.x];
+            rowstep[threadIdx.x] = active ? step : 0.f;
+            if (active) any_active[it % 3] = 1;
+        }
+        if (tol > 0.f) {
+            __syncthreads();
+            if (!any_active[it % 3]) break;
+        }
+        // ---- phase 2: X^T tile -= step * A^T tile . R^T, clamp ----
+        const float st = rowstep[i];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int c = wave + NW * t;
+            if (hi[t] <= lo[t]) continue;
+            f32x16 gt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gt[r] = 0.f;
+            const float* a2 = A2 + ((int64_t)c * (MP / 2)) * 64 + lane;
+            // four k-steps at a time, operands fetched together (the table is zero outside the
+            // tile's mels, so rounding the range outwards adds nothing)
+            for (int j = (lo[t] >> 1) & ~3; j < (hi[t] + 1) >> 1; j += 4) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = a2[(j + u) * 64];
+                    bv[u] = Rl[(2 * (j + u) + g) * 32 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gt = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], gt, 0, 0, 0);
+            }
+            GLV_SCHED_FENCE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xt[t][r] = fmaxf(xt[t][r] - st * gt[r], 0.f);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int c = wave + NW * t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int bin = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (row_ok && c < CT && bin < F) X[(row0 + i) * F + bin] = xt[t][r];
+        }
+    }
+}
+
 // Mel inversion fused with the set-up of the iteration state: for a block of 32 frames the
 // normalised-dB mel is turned into power once (LDS) and multiplied with the inverse basis on
 // the f32 MFMA, 32 bins per wave and step (the same fma chain as gemm_nt_kernel<true,

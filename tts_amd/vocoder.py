@@ -165,10 +165,11 @@ class GriffinLimPlan:
                                            _ptr(out), _stream_ptr(self.device)))
         return out
 
-    def mel_invert_nnls(self, mel_power, n_steps=200, power=2.0):
+    def mel_invert_nnls(self, mel_power, n_steps=200, power=2.0, tol=0.0):
         """(B, T, n_mels) mel POWER values -> (B, T, F) non-negative magnitudes: the
         mel_to_stft step of librosa.feature.inverse.mel_to_audio (reference
-        test_cnn_model.py:117-119) as a projected-gradient solver from librosa's start."""
+        test_cnn_model.py:117-119) as a projected-gradient solver from librosa's start.  A frame
+        stops once its mel residual is below ``tol`` times the norm of its mel (0: all steps)."""
         self._check(mel_power, (self.n_mels,), "mel_power")
         if mel_power.dim() != 3:
             raise ValueError("mel_power must be (B, T, n_mels)")
@@ -177,7 +178,7 @@ class GriffinLimPlan:
         b, t, _ = mel_power.shape
         out = torch.empty((b, t, self.n_bins), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.glv_mel_invert_nnls(self._handle, _ptr(mel_power), b, t, int(n_steps),
-                                                float(self._nnls_step), float(power), _ptr(out),
+                                                float(self._nnls_step), float(tol), float(power), _ptr(out),
                                                 _stream_ptr(self.device)))
         return out
 
