@@ -61,9 +61,23 @@ void emu_launch(const IterArgs& a) {
         constexpr int kRcArg = MODE == MODE_ITER_RC ? 1 : (MODE == MODE_ITER_RC_FIRST ? 2 : 0);
         constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z;
         constexpr int kNzh = MODE == MODE_ITER_LIN_Z ? Eng::NP / 2 : Eng::NP;
+        // runs of one workgroup (4 consecutive runs) hand their preloaded boundary blocks to the
+        // run before them, as the device kernel does through LDS (n_fft 1024, no metric)
+        std::vector<cf> shared(Eng::kShareFloats / 2 + 1);
+        bool take_next = false;
+        if (kLin && !SC && A == 1 && (ri % 4) != 3 && ri + 1 < a.n_runs && a.runs[ri + 1].utt == run.utt && !a.raw_in) {
+            std::vector<Eng> nx(64);
+            for (int l = 0; l < 64; ++l) {
+                nx[l].init(a, a.tables, l, a.runs[ri + 1]);
+                nx[l].template preload_lin<SC>(a);
+                if constexpr (A == 1) nx[l].publish_preload(shared.data());
+            }
+            take_next = true;
+        }
         if (kLin)
             for (int l = 0; l < 64; ++l) {
                 e[l].template preload_lin<SC>(a);
+                if (take_next) e[l].share_next = shared.data();
                 e[l].prefetch_block(a, run.t_begin);
                 e[l].prefetch_block_prev(a, run.t_begin);
                 e[l].template prefetch_s_pair<kNzh>(a, run.t_begin);

@@ -267,6 +267,7 @@ struct Engine {
         lane = lane_;
         run = r;
         block_extra = a.raw_in ? 1 : 0;
+        share_next = nullptr;
         tab.twA = tables;
         tab.twB = tab.twA + G::TW_A;
         tab.twC = tab.twB + G::TW_B;
@@ -327,6 +328,12 @@ struct Engine {
     // the signal proper is blocks [R/2, R/2 + T-1); block_extra = 1 where the block after it holds
     // the up to H-1 samples of a signal that is not a whole number of hops long (forward STFT)
     int block_extra = 0;
+    // Blocks t_end .. t_end+R-2, which this run's last frames need, are exactly the blocks the
+    // NEXT run of the same utterance loaded, completed and combined before its first frame.  When
+    // that run is a wave of the same workgroup it leaves them in LDS (share_next), and this run
+    // takes them from there instead of fetching both halves of both signals again.
+    const cf* share_next = nullptr;
+    GLV_HD bool from_next(int j) const { return share_next != nullptr && j >= run.t_end; }
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1 + block_extra; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
         return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
@@ -336,7 +343,7 @@ struct Engine {
     }
     GLV_HD void fetch_block_from(const IterArgs& a, const float* y_main, const float* y_tail, int j,
                                  BlockFetch& f) const {
-        const bool valid = block_valid(j);
+        const bool valid = block_valid(j) && !from_next(j);
         const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
         const float* pm = (valid && (a.raw_in || j < run.n_frames)) ? y_main + base : a.zeros;
         const float* pt = (valid && block_has_tail(a, j)) ? y_tail + base : a.zeros;
@@ -395,7 +402,7 @@ struct Engine {
     GLV_HD void prefetch_block_pair(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
         const int j = tt + R - 1;
-        const bool valid = block_valid(j);
+        const bool valid = block_valid(j) && !from_next(j);
         const bool has_main = valid && (a.raw_in || j < run.n_frames);
         const bool has_tail = valid && block_has_tail(a, j);
         const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
@@ -510,6 +517,23 @@ struct Engine {
         finish_block_w(a, blkp_n, blk_n.w, v, (R - 1) * HB);
         prefetch_block_pair(a, t + 1);
         combine_rows<SC, (R - 1) * HB, R * HB>(a.has_prev ? a.cmom : 0.0f);
+        if (from_next(t + R - 1)) take_shared(t + R - 1 - run.t_end);
+    }
+    // floats a run publishes: its R-1 preloaded blocks
+    static constexpr int kShareFloats = (R - 1) * H;
+    // rows [0, (R-1) HB) of the window after preload_lin -> LDS (n_fft 1024 form of the layout)
+    GLV_HD void publish_preload(cf* mine) const {
+        static_assert(A == 1, "only the n_fft 1024 kernels share boundary blocks");
+#pragma unroll
+        for (int row = 0; row < (R - 1) * HB; ++row) mine[row * (ROW / 2) + lane] = raw[row];
+    }
+    // block q of the next run's preload = this frame's newest block (the fetch delivered zeros)
+    GLV_HD void take_shared(int q) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const cf x = share_next[(q * HB + i) * (ROW / 2) + lane];
+            raw[(R - 1) * HB + i] = raw[(R - 1) * HB + i] + x;
+        }
     }
     // window one of the two arrays and start its forward transform
     GLV_HD void lin_window(const cf (&src)[E], cf* w) {

@@ -166,10 +166,18 @@ struct glv_plan {
 
 namespace {
 
+// LDS of one workgroup: tables, one exchange buffer per wave and (n_fft 1024) one set of shared
+// boundary blocks per wave
+template <int A, int HB>
+constexpr size_t engine_lds_bytes() {
+    using G = Geo<A>;
+    return (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf) +
+           (A == 1 ? (size_t)kWavesPerBlock * Engine<A, HB>::kShareFloats * sizeof(float) : 0);
+}
+
 template <int A, int HB>
 hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hipStream_t st) {
-    using G = Geo<A>;
-    const size_t lds = (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf);
+    const size_t lds = engine_lds_bytes<A, HB>();
     const dim3 g((unsigned)grid), b(64 * kWavesPerBlock);
     if (mode == MODE_ITER) {
         if (sc)
@@ -215,8 +223,7 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
 
 template <int A, int HB>
 int engine_blocks_per_cu_t() {
-    using G = Geo<A>;
-    const size_t lds = (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf);
+    const size_t lds = engine_lds_bytes<A, HB>();
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN, false>,
                                                      64 * kWavesPerBlock, lds) != hipSuccess)

@@ -35,6 +35,11 @@ constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 #ifndef GLV_PRIO
 #define GLV_PRIO 1
 #endif
+// 1: consecutive runs of one utterance that sit in one workgroup hand their boundary blocks over
+// through LDS (n_fft 1024 iteration kernels); 0: every run fetches its own.
+#ifndef GLV_SHARE_BOUNDARY
+#define GLV_SHARE_BOUNDARY 1
+#endif
 
 __device__ __forceinline__ void wave_sync() {
     // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
@@ -99,10 +104,16 @@ gl_engine_kernel(IterArgs a) {
     // threadIdx.x >> 6 (and everything loaded through it) is the same in all 64 lanes
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ri = blockIdx.x * kWavesPerBlock + wave;
-    if (ri >= a.n_runs) return;
+    // kernels whose waves hand boundary blocks to each other through LDS meet at a barrier after
+    // the preload: there a wave without a run has to stay until then
+    constexpr bool kShare = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC && A == 1 &&
+                            GLV_SHARE_BOUNDARY;
+    const bool live = ri < a.n_runs;
+    if (!live && !kShare) return;
     cf* xb = tables + G::TABLES + wave * G::XBUF;
+    cf* shared_blocks = tables + G::TABLES + kWavesPerBlock * G::XBUF;  // [wave][kShareFloats / 2]
 
-    RunDesc rd = a.runs[ri];
+    RunDesc rd = a.runs[live ? ri : 0];
     rd.utt = __builtin_amdgcn_readfirstlane(rd.utt);
     rd.t_begin = __builtin_amdgcn_readfirstlane(rd.t_begin);
     rd.t_end = __builtin_amdgcn_readfirstlane(rd.t_end);
@@ -155,8 +166,22 @@ gl_engine_kernel(IterArgs a) {
         e.preload_prev(a);
         e.prefetch_block_prev(a, e.run.t_begin);
     }
+    if constexpr (kShare) {
+        cf* mine = shared_blocks + wave * (Eng::kShareFloats / 2);
+        if (live) {
+            e.template preload_lin<SC>(a);
+            e.publish_preload(mine);
+        }
+        __syncthreads();
+        if (!live) return;
+        // the next run, if it continues this utterance inside this workgroup
+        if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
+            const int next_utt = __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt);
+            if (next_utt == e.run.utt) e.share_next = mine + Eng::kShareFloats / 2;
+        }
+    }
     if (kLin) {
-        e.template preload_lin<SC>(a);
+        if (!kShare) e.template preload_lin<SC>(a);
         e.prefetch_block(a, e.run.t_begin);
         e.prefetch_block_prev(a, e.run.t_begin);
         e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
