@@ -326,7 +326,13 @@ def main():
         p_half, f_bins, r_cover = N_FFT // 2, N_FFT // 2 + 1, N_FFT // HOP
         # bytes one launch of the iteration kernel cannot avoid (this rank's batch), and the
         # bytes of the unfused chain of the same iteration
-        fused_bytes = sum(t * (4 * p_half + 12 * HOP) + (r_cover - 1) * 12 * HOP for t in frames_list)
+        # (magnitudes: P floats per frame, or 3P/4 where the upper quarter of every lane's bins has
+        # all-zero rows in the inverse basis and the kernel neither stores nor fetches them)
+        from tts_amd.filters import inverse_mel_basis
+        nz_rows = np.nonzero(np.abs(inverse_mel_basis(SR, N_FFT, N_MELS, 0.0, FMAX)).sum(axis=1))[0]
+        first_skipped = (3 * p_half) // 4 if N_FFT == 1024 else 512 + 256
+        s_floats = (3 * p_half) // 4 if (int(nz_rows.max()) < first_skipped and not nnls and not args.unfused) else p_half
+        fused_bytes = sum(t * (4 * s_floats + 12 * HOP) + (r_cover - 1) * 12 * HOP for t in frames_list)
         unfused_bytes = sum(44 * f_bins * t + 8 * HOP * (t - 1) for t in frames_list)
         kernel_ms = float(np.mean(loop_ms)) / N_ITER
         achieved = fused_bytes / (kernel_ms * 1e-3) / 1e9
@@ -370,7 +376,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "bytes_model": "fused iteration: T*(4P + 12H) + (R-1)*12H per utterance and launch",
+                         "bytes_model": f"fused iteration: T*(4*{s_floats} + 12H) + (R-1)*12H per utterance and launch "
+                                        f"({s_floats} magnitudes per frame, P = {p_half})",
                          "alg_bytes_per_launch": fused_bytes,
                          "kernel_ms_per_launch": round(kernel_ms, 5),
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -39,7 +39,8 @@ if os.path.exists(path):
     old = json.load(open(path))
     if "entries" in old:
         doc = old
-for f in sorted(glob.glob(os.path.join(prof, f"{tag}*_rocprof_summary.json"))):
+files = glob.glob(os.path.join(prof, f"{tag}_rocprof_summary.json")) + glob.glob(os.path.join(prof, f"{tag}_*_rocprof_summary.json"))
+for f in sorted(files):
     d = json.load(open(f))
     if d.get("traffic_key") and d.get("gl_engine_iter_bytes_per_launch"):
         doc["entries"][d["traffic_key"]] = {
@@ -51,7 +52,7 @@ for f in sorted(glob.glob(os.path.join(prof, f"{tag}*_rocprof_summary.json"))):
 json.dump(doc, open(path, "w"), indent=1)
 PY
 # SQ / LDS counter summaries of the iteration kernel
-for d in "$ROOT"/gpurun_out/pmc_${TAG}*; do
+for d in "$ROOT"/gpurun_out/pmc_${TAG} "$ROOT"/gpurun_out/pmc_${TAG}_*; do
   [ -f "$d/summary.json" ] && cp "$d/summary.json" "$P/$(basename "$d" | sed "s/^pmc_//")_pmc_counters.json"
 done
 echo "profiles/ updated from $M"

@@ -1,14 +1,20 @@
 // Device kernels of libglvoc (gfx950), included once by glvoc.hip.
 //
 //   gl_engine_kernel    one wavefront per run of frames: STFT frame -> phase update -> inverse
-//                       FFT -> register overlap-add (engine.h).  Modes: full iteration, iSTFT
-//                       only, STFT only, the one-frame-per-wave forms for small batches, and
-//                       measurement variants.  HBM-bound by design: per frame it reads tprev
-//                       (8P B) + S (4P B) + H new samples and writes tprev (8P B) + H samples.
-//   mel_native_kernel   dB -> power -> f32 MFMA product with the inverse mel basis -> native
-//                       iteration state, fused.
-//   gemm_nt_kernel      the same product as a plain "NT" GEMM with selectable epilogues
-//                       (mel inversion, NNLS steps, forward mel projection).
+//                       FFT -> register overlap-add (engine.h).  Modes: the iteration with the
+//                       momentum term formed in the time domain (the default: per frame it reads
+//                       the target magnitudes and one hop of each of the two newest signals and
+//                       writes one hop; no spectrum is ever stored), the same in librosa's
+//                       frequency-domain form (keeps the previous spectrum in memory), iSTFT only,
+//                       STFT only, the one-frame-per-wave forms for small batches, and measurement
+//                       variants.
+//   mel_native_kernel   dB -> power -> f32 MFMA product with the inverse mel basis -> iteration
+//                       state (magnitudes in native or pair order, initial angles), fused.
+//   nnls_fused_kernel   all projected-gradient steps of the non-negative mel inversion in one
+//                       launch, the solution resident in registers in MFMA accumulator layout.
+//   gemm_nt_kernel      a plain "NT" GEMM on the f32 MFMA with selectable epilogues (mel
+//                       inversion with the reference's step boundary, the NNLS start and its
+//                       unfused steps, forward mel projection).
 //   init / convert / pad / finalize / peak / sc / power kernels: element-wise stages
 //                       (elementwise.h).
 #pragma once
