@@ -419,6 +419,11 @@ int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const flo
     });
 }
 
+// slot of native position (reg, lane) in a frame of magnitudes stored in pair order
+int emu_pair_s_slot(int n_fft, int nzh, int reg, int lane) {
+    return n_fft == 1024 ? pair_s_slot<1>(nzh, reg, lane) : pair_s_slot<2>(nzh, reg, lane);
+}
+
 // u[i] = the generator's value for element idx0 + i (the device-side initial phase stream)
 void emu_counter_uniform(uint64_t seed, uint64_t idx0, int n, float* u) {
     for (int i = 0; i < n; ++i) u[i] = counter_uniform(seed, idx0 + (uint64_t)i);

@@ -322,3 +322,28 @@ def test_zero_magnitude_bins_are_left_out(emu, n_fft, hop, win, frames, fpr):
     y4n, _ = emu_griffinlim(emu, to_btf(s), to_btf2(ph), [frames], n_fft, hop, win, 5, fpr, recompute=4,
                             want_sc=False)
     assert np.array_equal(y4, y4n)
+
+
+@pytest.mark.parametrize("n_fft,nzh", [(1024, 4), (1024, 2), (2048, 8), (2048, 4)])
+def test_pair_order_of_the_magnitudes_is_a_layout(emu, n_fft, nzh):
+    """Pair order gives every bin that can be non-zero exactly one slot inside the frame: the low
+    registers where native order has them, the mirrors of the last nzh pairs behind them, the
+    self-mirrored bin n_fft/4 next to the Nyquist bin; only registers from 3/4 up lose their slot
+    when nzh is half the pairs (lane 0's mirrors sit one register higher than everybody else's)."""
+    e, p = n_fft // 128, n_fft // 2
+    slots = {}
+    for reg in range(e):
+        for lane in range(64):
+            s = emu.emu_pair_s_slot(n_fft, nzh, reg, lane)
+            low = (lane >> 3) + 8 * (lane & 7)
+            if s < 0:
+                assert nzh < e // 2 and reg >= e // 2 + nzh + (1 if low == 0 else 0)
+                continue
+            assert 0 <= s < p + 4 and s not in slots and s != p
+            slots[s] = (reg, lane)
+            if reg < e // 2:
+                assert s == ((reg >> 2) * 64 + lane) * 4 + (reg & 3)
+    assert slots[p + 1] == (e // 2, 0)
+    # every native position when all mirrors are kept; otherwise the low half, nzh mirrors per
+    # lane and the self-mirrored bin
+    assert len(slots) == (64 * e if nzh == e // 2 else 32 * e + 64 * nzh + 1)

@@ -856,3 +856,63 @@ def test_batch_sharded_processes(backend, world):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "worst rel L2" in res.stdout
+
+
+def test_alternating_shapes_without_draining_the_stream(voc):
+    """A serving loop that alternates between batches of different lengths and iteration counts:
+    the run tables go up from pinned staging sets in rotation and the captured graphs of several
+    shapes stay cached, with no host wait in between - every repetition of a shape must give the
+    bits of its first occurrence, also when the calls are queued back to back."""
+    n_fft, hop = 1024, 256
+    f = n_fft // 2 + 1
+    rng = np.random.default_rng(41)
+    shapes = [([64, 40, 21], 5), ([30, 64], 3), ([12, 12, 12, 50], 5), ([64], 4), ([33, 7, 64, 20], 2)]
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, 64, 4)
+    plan.set_option("single_frame", 0)
+    cases = []
+    for lens, k in shapes:
+        s = np.zeros((len(lens), 64, f), np.float32)
+        p = np.zeros((len(lens), 64, f, 2), np.float32)
+        for b, t in enumerate(lens):
+            s[b, :t] = rng.standard_normal((t, f)) ** 2
+            ang = 2 * np.pi * rng.random((t, f))
+            p[b, :t, :, 0], p[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+        cases.append((lens, k, dev(s), dev(p)))
+    first = [plan.griffinlim(sd, lens, phase0=pd, n_iter=k).clone() for lens, k, sd, pd in cases]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):                      # 20 calls queued without a synchronisation
+        for lens, k, sd, pd in cases:
+            outs.append(plan.griffinlim(sd, lens, phase0=pd, n_iter=k))
+    torch.cuda.synchronize()
+    for i, y in enumerate(outs):
+        assert torch.equal(y, first[i % len(cases)]), i
+    plan.close()
+
+
+def test_reserved_workspace_covers_forced_modes(voc, O):
+    """glv_plan_reserve sets the partial-sum buffers of the one-frame-per-wave mode and the
+    partials of the convergence curve aside for a shape beyond what the automatic mode choice
+    uses; the calls that follow match the oracle."""
+    n_fft, hop, frames, batch = 1024, 256, 200, 24       # 4800 frames: automatic choice would use runs
+    f = n_fft // 2 + 1
+    rng = np.random.default_rng(43)
+    s = (rng.standard_normal((batch, frames, f)) ** 2).astype(np.float32)
+    ang = 2 * np.pi * rng.random((batch, frames, f))
+    p = np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, batch)
+    before = plan.workspace_bytes
+    plan.reserve(batch, frames, n_iter=100, single_frame=True)
+    assert plan.workspace_bytes > before
+    grown = plan.workspace_bytes
+    plan.set_option("single_frame", 1)
+    y, sc = plan.griffinlim(dev(s), phase0=dev(p), n_iter=100 // 10, return_sc=True)
+    assert plan.workspace_bytes == grown                 # nothing had to grow inside the call
+    for b in (0, batch - 1):
+        ref, sc_ref = O.griffinlim(np.ascontiguousarray(s[b].T), n_iter=10, hop_length=hop, win_length=n_fft,
+                                   init_phase=from_btf2(p[b]), return_sc=True)
+        assert rel_l2(y[b].cpu().numpy(), ref) < 1e-4
+        assert np.max(np.abs(sc[b].cpu().numpy() - sc_ref) / sc_ref) < 1e-4
+    with pytest.raises(Exception):
+        plan.reserve(batch + 1, frames)
+    plan.close()

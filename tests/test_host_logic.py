@@ -79,3 +79,24 @@ def test_wav_writer_matches_the_reference_files(tmp_path):
     from scipy.io import wavfile
     sr2, raw = wavfile.read(str(path))
     assert sr2 == 22050 and raw.dtype == np.int16 and np.array_equal(raw, float_to_pcm16(y))
+
+
+def test_bench_reports_measured_traffic_only_for_the_kernel_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a counter pass filed under the workload's key together
+    with a digest of the kernel sources; another workload, or sources that changed since, give
+    null and the reason."""
+    import json
+    import bench
+    key = bench.traffic_key(1024, 256, 64, 430, "fixed", "default")
+    assert key == "n_fft1024_hop256_b64_t430_fixed_default"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    assert bench.measured_traffic(key)[0] is None
+    monkeypatch.setattr(bench, "engine_source_digest", lambda: "abc")
+    doc = {"entries": {key: {"bytes_per_launch": 123, "engine_source_digest": "abc", "profile": "profiles/x.json"}}}
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(doc))
+    assert bench.measured_traffic(key) == (123, "profiles/x.json")
+    assert bench.measured_traffic(bench.traffic_key(2048, 256, 64, 865, "fixed", "default"))[0] is None
+    monkeypatch.setattr(bench, "engine_source_digest", lambda: "changed")
+    value, why = bench.measured_traffic(key)
+    assert value is None and "stale" in why
