@@ -554,6 +554,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 //   A2[c][j][lane]     = A[2 j + g][32 c + l % 32]
 //   mel_lo / mel_hi[c]   mels [lo, hi) with a non-zero entry in bin tile c
 // X0 (rows, F) in, X (rows, F) out, in place.
+#ifndef GLV_NNLS_PIPE1
+#define GLV_NNLS_PIPE1 1
+#endif
+#ifndef GLV_NNLS_PIPE2
+#define GLV_NNLS_PIPE2 1
+#endif
 template <int NW, int TPW, int MT>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(float* __restrict__ X, const float* __restrict__ Bmel,
                                                            const float* __restrict__ A1, const float* __restrict__ A2,
@@ -615,24 +621,52 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        // (the table pointers are made opaque once per step: the operand loads are the same in
+        // every step, and hoisted out of the step loop they would need a register each)
+        const float* A1s = A1;
+        const float* A2s = A2;
+        asm volatile("" : "+s"(A1s), "+s"(A2s));
+#if GLV_NNLS_PIPE1
+        // The TPW * MT (tile, mel tile) blocks in a fixed order; a block is skipped when no filter
+        // of the tile falls into the mel tile.  The operands of block n + 1 are requested before
+        // the matrix instructions of block n are issued, so their way from L2 is hidden behind
+        // 16 MFMAs; the fences keep the compiler from requesting all blocks at once.
+        auto active = [&](int n) { return hi[n / MT] > 32 * (n % MT) && lo[n / MT] < 32 * (n % MT + 1); };
+        auto request = [&](int n, float (&dst)[16]) {
+            const float* base = A1s + ((wave + NW * (n / MT)) * MT + n % MT) * (16 * 64);
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) dst[s2] = base[lane + s2 * 64];
+        };
+        float av[2][16];
+        if (active(0)) request(0, av[0]);
+#pragma unroll
+        for (int n = 0; n < TPW * MT; ++n) {
+            if (n + 1 < TPW * MT && active(n + 1)) request(n + 1, av[(n + 1) & 1]);
+            if (active(n)) {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2)
+                    acc[n % MT] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n & 1][s2], xt[n / MT][s2], acc[n % MT], 0, 0, 0);
+            }
+            GLV_SCHED_FENCE();
+        }
+#else
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const int c = wave + NW * t;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (hi[t] <= 32 * mt || lo[t] >= 32 * (mt + 1)) continue;  // no filter of this tile there
-                const float* a1 = A1 + ((int64_t)(c * MT + mt) * 16) * 64 + lane;
+                const float* a1 = A1s + ((c * MT + mt) * 16) * 64 + lane;
                 float av[16];
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) av[s2] = a1[s2 * 64];
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], xt[t][s2], acc[mt], 0, 0, 0);
-                // one block's operands at a time: the compiler would otherwise fetch those of all
-                // TPW * MT blocks ahead and run out of registers
                 GLV_SCHED_FENCE();
             }
         }
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -670,9 +704,34 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
             f32x16 gt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gt[r] = 0.f;
-            const float* a2 = A2 + ((int64_t)c * (MP / 2)) * 64 + lane;
-            // four k-steps at a time, operands fetched together (the table is zero outside the
-            // tile's mels, so rounding the range outwards adds nothing)
+            const float* a2 = A2s + c * (MP / 2) * 64 + lane;
+#if GLV_NNLS_PIPE2
+            // four k-steps at a time; the operands of the next four are requested before the
+            // matrix instructions of these four are issued (the table is zero outside the tile's
+            // mels, so rounding the range outwards adds nothing)
+            auto fetch = [&](int j, float (&av)[4], float (&bv)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = a2[(j + u) * 64];
+                    bv[u] = Rl[(2 * (j + u) + g) * 32 + i];
+                }
+            };
+            const int jend = (hi[t] + 1) >> 1;
+            float av[4], bv[4];
+            fetch((lo[t] >> 1) & ~3, av, bv);
+            for (int j = (lo[t] >> 1) & ~3; j < jend; j += 4) {
+                float an[4], bn[4];
+                fetch(j + 4 < MP / 2 ? j + 4 : j, an, bn);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gt = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], gt, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = an[u];
+                    bv[u] = bn[u];
+                }
+            }
+            GLV_SCHED_FENCE();
+#else
             for (int j = (lo[t] >> 1) & ~3; j < (hi[t] + 1) >> 1; j += 4) {
                 float av[4], bv[4];
 #pragma unroll
@@ -684,6 +743,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
                 for (int u = 0; u < 4; ++u) gt = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], gt, 0, 0, 0);
             }
             GLV_SCHED_FENCE();
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) xt[t][r] = fmaxf(xt[t][r] - st * gt[r], 0.f);
         }
