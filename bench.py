@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--lengths", choices=["fixed", "ljspeech"], default="fixed")
     ap.add_argument("--n-fft", type=int, default=N_FFT, help="n_fft = win_length (default workload: 1024)")
     ap.add_argument("--frames-per-run", type=int, default=0)
+    ap.add_argument("--run-target", type=int, default=0,
+                    help="number of runs the automatic run table aims at (default 0: the device's wave slots)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--recompute", type=int, default=-1,
                     help="1/0: force the iteration variant that recomputes the previous spectrum (default: library choice)")
@@ -238,6 +240,8 @@ def main():
     plan.set_utterance_ids(utt_ids)
     if fpr:
         plan.set_option("frames_per_run", fpr)
+    if args.run_target:
+        plan.set_option("run_target", args.run_target)
     if args.no_graph:
         plan.set_option("use_graph", 0)
     if args.traffic_only:
@@ -340,6 +344,8 @@ def main():
                    "recompute" if args.recompute == 1 else "spectral" if args.linear == 0 else "default")
         if fpr:
             variant += f"_fpr{fpr}"
+        if args.run_target:
+            variant += f"_target{args.run_target}"
         if args.single_frame >= 0:
             variant += f"_single{args.single_frame}"
         key = traffic_key(N_FFT, HOP, batch, args.frames, args.lengths, variant)

@@ -459,4 +459,9 @@ int emu_istft(int n_fft, int hop, int win_length, const float* D, const int* n_f
         return e.istft(D, y, y_stride);
     });
 }
+
+// the number of runs the automatic run table aims at (pick_run_target)
+int64_t emu_pick_run_target(int64_t total_frames, int cus, int waves_per_block, int blocks_per_cu, int min_len) {
+    return pick_run_target(total_frames, cus, waves_per_block, blocks_per_cu, min_len);
+}
 }

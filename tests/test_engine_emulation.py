@@ -234,6 +234,26 @@ def test_time_domain_momentum_drift_on_the_fixture(emu, lj001):
     assert np.max(np.abs(sc[0] - sc_ref) / sc_ref) < 1e-5
 
 
+def test_run_target_prefers_whole_workgroups_per_cu(emu):
+    """The automatic run count on a 256-CU device with 4-wave workgroups: never more than the wave
+    slots or than the minimum run length allows; a whole number of workgroups per CU where
+    the measured launch times say so (8 utterances of 430 frames: 1024 runs, not the 1146 the
+    minimum length allows; 16: 2048; 64: all 3072 slots); the longest table when that is cheaper
+    (12 utterances)."""
+    emu.emu_pick_run_target.restype = ctypes.c_int64
+    pick = lambda total, bpc, min_len: emu.emu_pick_run_target(ctypes.c_int64(total), 256, 4, bpc, min_len)
+    assert pick(430 * 8, 3, 3) == 1024
+    assert pick(430 * 12, 3, 3) == 430 * 12 // 3
+    assert pick(430 * 16, 3, 3) == 2048
+    assert pick(430 * 64, 3, 3) == 3072
+    assert pick(865 * 8, 2, 7) == 865 * 8 // 7
+    assert pick(865 * 32, 2, 7) == 2048
+    for total in (2, 7, 100, 3071, 3072, 3073, 50000, 196608):
+        for bpc, min_len in ((3, 3), (2, 7), (1, 1)):
+            t = pick(total, bpc, min_len)
+            assert 1 <= t <= min(256 * 4 * bpc, max(1, total // min_len))
+
+
 @pytest.mark.parametrize("lens,target,r", [([430] * 64, 3072, 4), ([430] * 64, 4096, 4), ([865] * 64, 2048, 8),
                                            ([97, 3, 640, 12, 2, 311], 100, 4), ([5, 5, 5], 64, 4),
                                            ([865], 2048, 8), ([2, 2], 1, 2)])

@@ -53,6 +53,8 @@ struct glv_plan {
     // options
     int frames_per_run = 0;  // 0 = choose from the batch and the device's wave slots
     int wave_slots = 2048;   // runs the device holds at once (CUs x resident blocks x waves)
+    int run_target = 0;      // number of runs asked for when frames_per_run is 0 (0 = pick_run_target)
+    int n_cus = 256, blocks_per_cu = 2;
     int use_graph = 1;
     int timing = 0;
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
@@ -127,7 +129,7 @@ struct glv_plan {
     int stage_next = 0;
     size_t max_runs = 0;
     std::vector<int> cur_nframes;
-    int cur_frames_stride = -1, cur_fpr = -1, n_runs = 0;
+    int cur_frames_stride = -1, cur_fpr = -1, cur_target = -1, n_runs = 0;
     // graph cache for the iteration loop: the most recently used shapes stay instantiated, so a
     // serving loop that alternates between a few batch shapes replays instead of re-capturing
     struct GraphKey {
@@ -447,7 +449,8 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
             return fail(GLV_ERR_INVALID, "n_frames[%d] = %d outside [2, %d]", b, n_frames_host[b],
                         frames_stride);
     const bool same = (int)p->cur_nframes.size() == batch && p->cur_frames_stride == frames_stride &&
-                      p->cur_fpr == p->frames_per_run && p->cur_single == single &&
+                      p->cur_fpr == p->frames_per_run && p->cur_target == p->run_target &&
+                      p->cur_single == single &&
                       memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
     if (same) return GLV_OK;
     std::vector<RunDesc> runs;
@@ -464,7 +467,11 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         for (int b = 0; b < batch; ++b) total += n_frames_host[b];
         const int64_t slots = p->wave_slots;
         const int64_t rounds = std::max<int64_t>(1, (total + slots * 64 - 1) / (slots * 64));
-        runs = build_runs_target(n_frames_host, batch, slots * rounds, p->R);
+        const int64_t target = p->run_target > 0 ? p->run_target
+                               : rounds > 1      ? slots * rounds
+                                                 : pick_run_target(total, p->n_cus, kWavesPerBlock,
+                                                                   p->blocks_per_cu, std::max(1, p->R - 1));
+        runs = build_runs_target(n_frames_host, batch, target, p->R);
     }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
     std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);
@@ -494,6 +501,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     p->cur_nframes.assign(n_frames_host, n_frames_host + batch);
     p->cur_frames_stride = frames_stride;
     p->cur_fpr = p->frames_per_run;
+    p->cur_target = p->run_target;
     p->cur_single = single;
     p->n_runs = (int)runs.size();
     return GLV_OK;
@@ -561,8 +569,11 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
 
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            p->wave_slots = prop.multiProcessorCount * p->engine_blocks_per_cu() * kWavesPerBlock;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            p->n_cus = std::max(1, prop.multiProcessorCount);
+            p->blocks_per_cu = p->engine_blocks_per_cu();
+            p->wave_slots = p->n_cus * p->blocks_per_cu * kWavesPerBlock;
+        }
     }
     const size_t frames = (size_t)max_batch * max_frames;
     const size_t ylen = (size_t)max_batch * p->blocks * hop;
@@ -623,7 +634,9 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
         int rc = ensure_parts(p, (size_t)2 * p->R * pad_blocks * hop, nullptr);
         if (rc == GLV_OK)
             rc = ensure_sc(p, (size_t)64 * 2 * std::max(runs_bound(p, (int64_t)frames, false),
-                                                        (size_t)std::min<int64_t>((int64_t)frames, 2 * (int64_t)p->wave_slots)),
+                                                        (size_t)std::min<int64_t>((int64_t)frames,
+                                                                                 std::max<int64_t>(2 * (int64_t)p->wave_slots,
+                                                                                                   (int64_t)(8 + 2 * p->A) * p->n_cus))),
                            nullptr);
         if (rc != GLV_OK) {
             plan_free(p);
@@ -648,6 +661,9 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     if (!strcmp(name, "frames_per_run")) {
         if (value < 0) return fail(GLV_ERR_INVALID, "frames_per_run must be >= 0 (0 = automatic)");
         p->frames_per_run = value;
+    } else if (!strcmp(name, "run_target")) {
+        if (value < 0) return fail(GLV_ERR_INVALID, "run_target must be >= 0 (0 = automatic)");
+        p->run_target = value;
     } else if (!strcmp(name, "linear")) {
         p->linear = value != 0;
         drop_graphs(p);
@@ -976,17 +992,18 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
     if (batch < 1 || batch > p->max_batch)
         return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
-    // A batch with about as many frames as the device has wave slots, or fewer, cannot fill it
-    // with runs of several frames: every frame then gets a wave of its own (partial-sum buffers
-    // instead of a running sum; measured faster up to 1.1x the slots, slower from 1.7x).  Not for
-    // layouts so ragged that the padded buffers would dwarf the payload.
+    // A batch of few frames cannot fill the device with runs of several frames: every frame then
+    // gets a wave of its own (partial-sum buffers instead of a running sum).  Measured against the
+    // best run table: faster up to about 10 frames per CU at n_fft 1024 and 12 at n_fft 2048 (6.2
+    // against 10.8 us per launch for one utterance of 430 frames), slower beyond.  Not for layouts
+    // so ragged that the padded buffers would dwarf the payload.
     int64_t total_frames = 0;
     for (int b = 0; b < batch; ++b) total_frames += std::max(0, n_frames_host[b]);
     const int64_t padded_blocks = (int64_t)batch * (frames_stride + p->R);
     const bool plain = !p->recompute && !p->traffic_only && !p->alias_utts;
     const bool single = plain && (p->single_frame == 1 ||
                                   (p->single_frame < 0 && p->frames_per_run == 0 &&
-                                   4 * total_frames <= 5 * (int64_t)p->wave_slots &&
+                                   total_frames <= (int64_t)(8 + 2 * p->A) * p->n_cus &&
                                    padded_blocks <= 4 * (int64_t)p->wave_slots));
     int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single);
     if (rc != GLV_OK) return rc;

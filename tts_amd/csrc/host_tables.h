@@ -175,6 +175,40 @@ inline std::vector<RunDesc> build_runs_target(const int* n_frames, int batch, in
     return runs;
 }
 
+// How many runs the automatic run table should aim at when the batch fits the device's wave
+// slots in one round (total frames <= 64 x slots).  Measured on MI355X (launch time of the
+// iteration kernel against the target, batches of 8..64 utterances, both n_fft): a wave that
+// walks L frames costs about (L + 4) frame times (preloading the blocks before its first
+// frame, finishing the blocks after its last), and a frame time grows with the workgroups
+// resident on a CU as 1 : 1.32 : 1.63 for 1 : 2 : 3.  Launches whose workgroups are a whole
+// multiple of the CUs come out best; between multiples the slowest CU carries the next whole
+// number while the others run lighter, which the average of the two figures describes within
+// 1-2 % of the measurements.  The candidates are k x CUs workgroups for every k that leaves
+// runs of at least min_len frames, and the largest table the minimum length allows.
+inline int64_t pick_run_target(int64_t total_frames, int cus, int waves_per_block, int blocks_per_cu, int min_len) {
+    const int64_t slots = (int64_t)cus * waves_per_block * blocks_per_cu;
+    const int64_t cap = std::max<int64_t>(1, total_frames / std::max(1, min_len));
+    auto frame_time = [](double k) { return 1.0 + 0.315 * (k - 1.0); };
+    auto cost = [&](int64_t runs) {
+        const double per_cu = (double)((runs + waves_per_block - 1) / waves_per_block) / cus;
+        const double k = std::max(1.0, per_cu);
+        const double t = 0.5 * (frame_time(std::ceil(k)) + frame_time(k));
+        return ((double)total_frames / (double)runs + 4.0) * t;
+    };
+    int64_t best = std::min(cap, slots);
+    double best_cost = cost(best);
+    for (int k = 1; k <= blocks_per_cu; ++k) {
+        const int64_t runs = (int64_t)k * cus * waves_per_block;
+        if (runs > cap) break;
+        const double c = cost(runs);
+        if (c < best_cost) {
+            best_cost = c;
+            best = runs;
+        }
+    }
+    return best;
+}
+
 // tail_flag[b*blocks_stride + j] = 1 when block j of utterance b is completed by
 // adding the tail buffer (first R-1 blocks after an interior run boundary, and
 // the R-1 blocks past the last frame).
