@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--lengths", choices=["fixed", "ljspeech"], default="fixed")
     ap.add_argument("--n-fft", type=int, default=N_FFT, help="n_fft = win_length (default workload: 1024)")
     ap.add_argument("--frames-per-run", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="plan option set before the run (glv_plan_set_option), e.g. fuse_draw=0; may repeat")
     ap.add_argument("--run-target", type=int, default=0,
                     help="number of runs the automatic run table aims at (default 0: the device's wave slots)")
     ap.add_argument("--no-graph", action="store_true")
@@ -242,6 +244,9 @@ def main():
         plan.set_option("frames_per_run", fpr)
     if args.run_target:
         plan.set_option("run_target", args.run_target)
+    for item in args.option:
+        name, _, value = item.partition("=")
+        plan.set_option(name, int(value))
     if args.no_graph:
         plan.set_option("use_graph", 0)
     if args.traffic_only:
@@ -346,6 +351,8 @@ def main():
             variant += f"_fpr{fpr}"
         if args.run_target:
             variant += f"_target{args.run_target}"
+        for item in sorted(args.option):
+            variant += "_" + item.replace("=", "")
         if args.single_frame >= 0:
             variant += f"_single{args.single_frame}"
         key = traffic_key(N_FFT, HOP, batch, args.frames, args.lengths, variant)

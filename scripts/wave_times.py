@@ -36,9 +36,13 @@ def main():
     lib.glv_debug_wave_times.restype = ctypes.c_int
     lib.glv_debug_wave_times.argtypes = [ctypes.c_void_p, ctypes.c_int]
     n = 16384
-    raw = np.zeros((n, 20), np.uint64)
+    raw = np.zeros((n, 20), np.uint64)  # 18 stamps + 2 shader-clock readings per wave
     assert lib.glv_debug_wave_times(raw.ctypes.data, n) == 0
     raw = raw[raw[:, 3] > 0].astype(np.int64)
+    shader = (raw[:, 19] - raw[:, 18]) / np.maximum(1, raw[:, 3] - raw[:, 0]) * 100.0   # cycles per microsecond
+    print(f"shader clock while the waves ran: median {np.median(shader):.0f} MHz  p10 {np.percentile(shader, 10):.0f}  "
+          f"p90 {np.percentile(shader, 90):.0f}")
+    raw = raw[:, :18]
     t = (raw - raw[:, 0].min()) / 100.0          # microseconds since the first wave started
     t[raw == 0] = np.nan
     print(f"waves {len(t)}")

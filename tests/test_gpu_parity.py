@@ -916,3 +916,38 @@ def test_reserved_workspace_covers_forced_modes(voc, O):
     with pytest.raises(Exception):
         plan.reserve(batch + 1, frames)
     plan.close()
+
+
+@pytest.mark.parametrize("n_fft,hop,lens,ids", [(1024, 256, [64, 40, 21, 2, 9], None), (1024, 256, [33, 64], [7, 123456789012]),
+                                                (2048, 256, [48, 30, 5], None), (2048, 512, [40, 17], [3, 1]),
+                                                (1024, 128, [50, 12], None)])
+def test_phase_drawn_inside_the_first_inverse_equals_stored_spectrum(voc, n_fft, hop, lens, ids):
+    """With no phase given, the run-based iteration that keeps no spectrum lets the first inverse
+    transform draw the initial phase itself (nothing stored); switched off, the set-up kernels
+    store S * phase and that kernel reads it back.  Same products in the same order: the
+    waveforms must agree bit for bit - from mel input (pair order without the bins that are zero
+    for good) and from caller magnitudes (pair order, all bins), and also after 0 iterations,
+    where the output is the inverse of the initial spectrum itself."""
+    f = n_fft // 2 + 1
+    t_max, b = max(lens), len(lens)
+    rng = np.random.default_rng(47)
+    mel = np.stack([np.pad(synthetic_mel(500 + i, t), ((0, t_max - t), (0, 0))) for i, t in enumerate(lens)])
+    s = np.zeros((b, t_max, f), np.float32)
+    for i, t in enumerate(lens):
+        s[i, :t] = rng.standard_normal((t, f)) ** 2
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t_max, b)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    plan.set_option("single_frame", 0)
+    plan.set_utterance_ids(ids)
+    got = {}
+    for fuse in (1, 0):
+        plan.set_option("fuse_draw", fuse)
+        for k in (0, 3):
+            got[fuse, k, "mel"] = plan.mel_to_audio(dev(mel), MEAN, STD, lens, seed=99, n_iter=k).clone()
+            got[fuse, k, "s"] = plan.griffinlim(dev(s), lens, seed=5, n_iter=k).clone()
+    for k in (0, 3):
+        for src in ("mel", "s"):
+            y1, y0 = got[1, k, src], got[0, k, src]
+            assert float(y1.abs().max()) > 0
+            assert torch.equal(y1, y0), (k, src)
+    plan.close()

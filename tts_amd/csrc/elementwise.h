@@ -47,15 +47,17 @@ GLV_HD void init_native_element(const LayoutArgs& L, const float* S_nat, const c
         if (phase_nat) return phase_nat[fr * L.F + kk];
         return drawn_phase(L, seed, b, t, kk);
     };
+    if (q == 0) {
+        snat[L.P] = srow[L.P];
+        if (!L.s_pair_nzh) snat[L.P + 1] = 0.f;  // pair order keeps the bin P/2 there
+        snat[L.P + 2] = snat[L.P + 3] = 0.f;
+    }
+    if (!spec) return;  // the first inverse transform draws the phase itself (Engine::ph3_draw)
     const cf p = phase_at(k);
     cf ang = cf{p.x * s * inv_n, p.y * s * inv_n};
     if (q == 0) {
-        const float s_nyq = srow[L.P];
-        snat[L.P] = s_nyq;
-        if (!L.s_pair_nzh) snat[L.P + 1] = 0.f;  // pair order keeps the bin P/2 there
-        snat[L.P + 2] = snat[L.P + 3] = 0.f;
         const cf pn = phase_at(L.P);
-        ang = cf{p.x * s * inv_n, pn.x * s_nyq * inv_n};  // c2r ignores Im of DC / Nyquist
+        ang = cf{p.x * s * inv_n, pn.x * srow[L.P] * inv_n};  // c2r ignores Im of DC / Nyquist
     }
     spec[fr * L.P + native_spec_index(reg, lane)] = ang;
 }

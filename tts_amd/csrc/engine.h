@@ -124,6 +124,12 @@ struct IterArgs {
     float inv_n;              // 1 / n_fft
     int has_prev;             // 0 on the first iteration (no momentum term)
     int raw_in;               // y_in holds the padded signal itself (glv_stft)
+    // MODE_ISTFT / MODE_ISTFT1 without a stored initial spectrum: angles = S * phase drawn here
+    int draw;                 // 1: `spec` holds nothing, the initial phase is drawn in the kernel
+    int draw_nzh;             // layout of S: 0 native order, else pair order (pair_s_slot)
+    uint64_t draw_seed;
+    const int64_t* draw_ids;  // [batch] utterance identities of the phase stream, or null: the row
+    int64_t draw_origin;      // global index of local frame 0
 };
 
 // Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
@@ -200,6 +206,12 @@ GLV_HD const float* iwss_row(const float* iwss, const float* iwss_head, const fl
     const int jj = j < 2 * R ? j : 2 * R - 1;
     return iwss_small + ((int64_t)(T < R - 1 ? T : R - 2) * 2 * R + jj) * H;
 }
+
+// defined after the engine; used by its on-the-spot initial spectrum (ph3_draw)
+GLV_HD int native_s_index(int reg, int lane);
+template <int A>
+GLV_HD int pair_s_slot(int nzh, int reg, int lane);
+GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx);
 
 template <int A, int HB>
 struct Engine {
@@ -851,7 +863,33 @@ struct Engine {
     }
 
     // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
-    GLV_HD void ph3_load(const IterArgs& a, int t) { load_spec(a, t, v); }
+    GLV_HD void ph3_load(const IterArgs& a, int t) {
+        if (a.draw)
+            ph3_draw(a, t);
+        else
+            load_spec(a, t, v);
+    }
+    // The initial spectrum of frame t made on the spot: magnitude (wherever the layout of S keeps
+    // it; bins without a slot are zero) times the phase drawn for (utterance, frame, bin), scaled
+    // by 1/n_fft like the stored form - the same products in the same order, so the same bits.
+    GLV_HD void ph3_draw(const IterArgs& a, int t) {
+        const uint64_t id = a.draw_ids ? (uint64_t)a.draw_ids[run.utt] : (uint64_t)run.utt;
+        const uint64_t key = a.draw_seed ^ (id * 0x9E3779B97F4A7C15ull);
+        const uint64_t first = (uint64_t)((t + a.draw_origin) * (P + 1));
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+#pragma unroll
+        for (int reg = 0; reg < E; ++reg) {
+            const int slot = a.draw_nzh ? pair_s_slot<A>(a.draw_nzh, reg, lane) : native_s_index(reg, lane);
+            const float s = slot >= 0 ? sf[slot] : 0.0f;
+            const cf ph = counter_phasor(key, first + (uint64_t)G::bin(reg, lane));
+            v[reg] = cf{ph.x * s * a.inv_n, ph.y * s * a.inv_n};
+        }
+        if (lane == 0) {
+            // DC and Nyquist are real and share native bin 0 (the inverse ignores their Im)
+            const cf pn = counter_phasor(key, first + (uint64_t)P);
+            v[0].y = pn.x * sf[P] * a.inv_n;
+        }
+    }
 
     GLV_HD void ph3_write(cf* w) { F::mirror_store(v, w, lane); }
 

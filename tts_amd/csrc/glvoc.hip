@@ -60,6 +60,7 @@ struct glv_plan {
     int traffic_only = 0;  // measurement aid: iteration launches move data but compute nothing
     int recompute = 0;     // iterate without the spectrum state in HBM (MODE_ITER_RC)
     int alias_utts = 0;    // measurement aid: all utterances share one utterance's memory
+    int fuse_draw = 1;     // device-drawn phase made inside the first inverse transform (no stored spectrum)
     int zero_skip = 1;     // leave out the bins whose inverse-basis rows vanish (MODE_ITER_LIN_Z)
     int kmax_bin = 1 << 30;  // highest bin with a non-zero row in the inverse basis
     int cur_nzh = 0;       // pair-order parameter of the call in progress (0: native order)
@@ -163,7 +164,7 @@ struct glv_plan {
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
     void (*launch_power)(const ElemArgs&, const cf*, float*, hipStream_t) = nullptr;
     hipError_t (*launch_mel_native)(const glv_plan*, const ElemArgs&, const float*, float, float, const cf*,
-                                    uint64_t, float, unsigned*, hipStream_t) = nullptr;
+                                    uint64_t, float, cf*, unsigned*, hipStream_t) = nullptr;
 };
 
 namespace {
@@ -268,13 +269,13 @@ void launch_power_t(const ElemArgs& ea, const cf* spec, float* power, hipStream_
 
 template <int A>
 hipError_t launch_mel_native_t(const glv_plan* p, const ElemArgs& ea, const float* mel_db, float mean,
-                               float std_, const cf* phase, uint64_t seed, float inv_n, unsigned* peak_bits,
-                               hipStream_t st) {
+                               float std_, const cf* phase, uint64_t seed, float inv_n, cf* spec,
+                               unsigned* peak_bits, hipStream_t st) {
     const int64_t rows = (int64_t)ea.batch * ea.L.frames_stride;
     const size_t lds = (size_t)(32 * (p->Mp + 1) + 32 * kMelTileStride + 32) * sizeof(float);
     hipLaunchKernelGGL((mel_native_kernel<A>), dim3((unsigned)((rows + 31) / 32)), dim3(64 * kMelWaves), lds, st, ea,
                        mel_db, p->d_pinv_t, p->n_mels, p->Mp, p->Fp, mean, std_, phase, seed, inv_n, p->d_S,
-                       p->d_spec, peak_bits);
+                       spec, peak_bits);
     return hipGetLastError();
 }
 
@@ -671,6 +672,8 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->nnls_fused = value != 0;
     } else if (!strcmp(name, "zero_skip")) {
         p->zero_skip = value != 0;
+    } else if (!strcmp(name, "fuse_draw")) {
+        p->fuse_draw = value != 0;
     } else if (!strcmp(name, "single_frame")) {
         if (value < -1 || value > 1) return fail(GLV_ERR_INVALID, "single_frame must be -1 (automatic), 0 or 1");
         p->single_frame = value;
@@ -1032,17 +1035,28 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     ElemArgs ea = elem_args(p, batch, frames_stride);
     ea.L.s_pair_nzh = p->cur_nzh;
     const float inv_n = 1.0f / (float)p->n_fft;
+    // With a device-drawn phase and an iteration that keeps no spectrum, the initial spectrum
+    // S * phase is needed once, by the first inverse transform: that kernel draws the phase
+    // itself and nothing is stored (8 P bytes per frame neither written nor read back).
+    const bool fuse_draw = p->fuse_draw && lin_runs && phase0_dev == nullptr;
+    cf* spec0 = fuse_draw ? nullptr : p->d_spec;
     if (src.S_dev) {
-        p->launch_init(ea, src.S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, p->d_spec,
-                       st);
+        p->launch_init(ea, src.S_dev, reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, p->d_S, spec0, st);
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(p->launch_mel_native(p, ea, src.mel_db_dev, src.mean, src.std_,
-                                     reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, peak_bits, st));
+                                     reinterpret_cast<const cf*>(phase0_dev), seed, inv_n, spec0, peak_bits, st));
     }
 
     // inverse = istft(angles) of the initial phase
     IterArgs a = iter_args(p, frames_stride);
+    if (fuse_draw) {
+        a.draw = 1;
+        a.draw_nzh = p->cur_nzh;
+        a.draw_seed = seed;
+        a.draw_ids = ea.L.utt_ids;
+        a.draw_origin = ea.L.frame_origin;
+    }
     if (single) {
         set_parts_io(p, a, 1, 0);
         HIP_TRY(p->launch_engine(MODE_ISTFT1, false, a, engine_grid(p), st));
@@ -1050,6 +1064,11 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         set_io(p, a, 1, 0);
         HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     }
+    // the iteration launches do not look at these; cleared so that a captured graph holds no seed
+    a.draw = a.draw_nzh = 0;
+    a.draw_seed = 0;
+    a.draw_ids = nullptr;
+    a.draw_origin = 0;
 
     const float cmom = momentum / (1.0f + momentum);
     if (p->timing) HIP_TRY(hipEventRecord(p->ev0, st));

@@ -64,12 +64,14 @@ __device__ __forceinline__ void wave_sync() {
 #define GLV_MIN_WAVES_A2 2
 #endif
 #ifdef GLV_WAVE_TIMES
-// measurement build: every wave of the iteration kernel leaves four time stamps (100 MHz clock)
+// measurement build: every wave of the iteration kernel leaves time stamps (100 MHz clock; slots 18 and
+// 19: the shader clock at its start and end)
 __device__ unsigned long long glv_wave_times[20 * 16384];
 #define GLV_STAMP(k)                                                                          \
     if ((MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ITER1) && (threadIdx.x & 63) == 0) {           \
         const int w_ = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);                      \
-        if (w_ < 16384 && (k) < 20) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
+        if (w_ < 16384 && (k) < 18) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
+        if (w_ < 16384 && ((k) == 0 || (k) == 3)) glv_wave_times[20 * w_ + 18 + ((k) == 3)] = clock64(); \
     }
 #else
 #define GLV_STAMP(k)
@@ -860,6 +862,7 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
                 // (the first half of the registers), in the same place
                 if (!nzh || 8 * h + 4 * g < E / 2)
                     reinterpret_cast<f4*>(snat)[(2 * h + g) * 64 + lane] = f4{s4[0], s4[1], s4[2], s4[3]};
+                if (!spec) continue;  // the first inverse transform draws the phase itself (Engine::ph3_draw)
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const int ka = 512 * h + low + 64 * (4 * g + 2 * pp);
