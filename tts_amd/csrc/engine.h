@@ -213,7 +213,10 @@ template <int A>
 GLV_HD int pair_s_slot(int nzh, int reg, int lane);
 GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx);
 
-template <int A, int HB>
+// TWR: the twiddles of the first and second FFT pass stay in registers for the whole run as
+// well (n_fft 1024 only; 26 more registers, 12 fewer 16-byte LDS reads per frame) - for the
+// kernels whose register budget leaves room for them at three waves per SIMD.
+template <int A, int HB, bool TWR = false>
 struct Engine {
     using G = Geo<A>;
     using F = WaveFft<A>;
@@ -254,9 +257,10 @@ struct Engine {
 #ifndef GLV_TWIDDLES_IN_REGS
 #define GLV_TWIDDLES_IN_REGS 0
 #endif
-    // the FFT pass twiddles as well: measured no faster (28 more registers, two waves per SIMD
-    // instead of three), so off
-    static constexpr bool kRegTw = kRegTab && GLV_TWIDDLES_IN_REGS;
+    // the FFT pass twiddles as well (TWR): 26 more registers, which the time-domain-momentum
+    // kernels can afford at three waves per SIMD (38.7 against 39.9 us per launch) and the
+    // others cannot (GLV_TWIDDLES_IN_REGS forces them on everywhere, for experiments)
+    static constexpr bool kRegTw = kRegTab && (TWR || GLV_TWIDDLES_IN_REGS);
     cf twa_r[kRegTw ? 8 : 1];
     cf twb_r[kRegTw ? 8 : 1];
     GLV_HD const cf* twa_regs() const { return kRegTw ? twa_r : nullptr; }

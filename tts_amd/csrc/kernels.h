@@ -81,7 +81,8 @@ template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
     using G = Geo<A>;
-    using Eng = Engine<A, HB>;
+    // the default iteration kernels have registers to spare for the pass twiddles
+    using Eng = Engine<A, HB, (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tables = reinterpret_cast<cf*>(smem);
     GLV_STAMP(0)
