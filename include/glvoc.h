@@ -269,14 +269,16 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 /*
  * Tuning and measurement hooks (no counterpart in the reference).
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
+ *                        "run_target" (number of runs the automatic run table aims at; 0 = chosen
+ *                        from the batch and the device: whole workgroups per compute unit),
  *                        "linear" (1/0, default 1: form the momentum term in the time domain -
  *                        rebuilt_k - c*rebuilt_{k-1} = STFT(y_k - c*y_{k-1}) - so that no spectrum
  *                        state is kept in memory; 0 = subtract the stored previous spectrum as
  *                        librosa writes it; equal up to rounding),
  *                        "single_frame" (-1 automatic / 0 / 1: give every frame a wavefront of its
  *                        own - R partial-sum buffers instead of a running sum - which is what a
- *                        batch with fewer frames than the device has wave slots needs; automatic
- *                        only while "frames_per_run" is 0),
+ *                        batch of only a few frames per compute unit needs; automatic only while
+ *                        "frames_per_run" is 0),
  *                        "use_graph" (0/1: replay the iteration loop from a hipGraph),
  *                        "timing" (0/1: bracket the iteration loop with hipEvents),
  *                        "recompute" (0/1: iterate without the spectrum state in memory - the
@@ -287,6 +289,9 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
  *                        garbage),
  *                        "zero_skip" (1/0, default 1: the iteration leaves out the bins whose rows of the
  *                        inverse basis are all zero - their magnitudes are exactly zero),
+ *                        "fuse_draw" (1/0, default 1: with no phase0 and "linear" on, the first inverse
+ *                        transform draws the initial phase itself and S*phase is never stored;
+ *                        0 = the set-up kernel stores it; same bits either way),
  *                        "nnls_fused" (1/0, default 1: all steps of glv_mel_invert_nnls in one launch
  *                        with the solution resident in registers; 0 = two launches per step),
  *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue

@@ -257,14 +257,20 @@ struct Engine {
 #ifndef GLV_TWIDDLES_IN_REGS
 #define GLV_TWIDDLES_IN_REGS 0
 #endif
+#ifndef GLV_TWB_IN_REGS_A2
+#define GLV_TWB_IN_REGS_A2 1
+#endif
     // the FFT pass twiddles as well (TWR): 26 more registers, which the time-domain-momentum
     // kernels can afford at three waves per SIMD (38.7 against 39.9 us per launch) and the
     // others cannot (GLV_TWIDDLES_IN_REGS forces them on everywhere, for experiments)
     static constexpr bool kRegTw = kRegTab && (TWR || GLV_TWIDDLES_IN_REGS);
+    // n_fft 2048: only the second pass's (one set serves both sub-sequences; 249 of the 256
+    // registers two waves per SIMD can have, 148.3 -> 146.5 us per launch)
+    static constexpr bool kRegTwB = kRegTw || (A == 2 && TWR && GLV_TWB_IN_REGS_A2);
     cf twa_r[kRegTw ? 8 : 1];
-    cf twb_r[kRegTw ? 8 : 1];
+    cf twb_r[kRegTwB ? 8 : 1];
     GLV_HD const cf* twa_regs() const { return kRegTw ? twa_r : nullptr; }
-    GLV_HD const cf* twb_regs() const { return kRegTw ? twb_r : nullptr; }
+    GLV_HD const cf* twb_regs() const { return kRegTwB ? twb_r : nullptr; }
     GLV_HD const cf* twp_regs() const { return kRegTab ? twp_r : nullptr; }
     GLV_HD void load_window_lds(cf (&w)[E]) const {
 #pragma unroll
@@ -291,15 +297,17 @@ struct Engine {
         tab.win = tab.twP + G::TW_P;
         mbase = G::mirror_base(lane);
         if (kRegTw) {
-            cf ta[8], tb[8];
+            cf ta[8];
             G::load8(tab.twA, 0, lane, ta);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) twa_r[k % (kRegTw ? 8 : 1)] = ta[k];
+        }
+        if (kRegTwB) {
+            cf tb[8];
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) G::load2_8(tab.twB, kp, lane & 7, tb[2 * kp], tb[2 * kp + 1]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                twa_r[k % (kRegTw ? 8 : 1)] = ta[k];
-                twb_r[k % (kRegTw ? 8 : 1)] = tb[k];
-            }
+            for (int k = 0; k < 8; ++k) twb_r[k % (kRegTwB ? 8 : 1)] = tb[k];
         }
         if (kRegTab) {
             cf w[E];
