@@ -267,6 +267,36 @@ int glv_shard_output_range(const glv_plan* plan, int64_t* n_begin, int64_t* n_co
 int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 
 /*
+ * The swap done by the library itself: RCCL point-to-point on the caller's stream, between
+ * glv_shard_begin / glv_shard_step and the next step, with no host wait (the reference has no
+ * counterpart; BASELINE's long-form configuration names this exchange).  One process per GPU,
+ * rank r holds shard r of `world` consecutive shards.  A glv_halo is this process's place in
+ * that chain (an RCCL communicator); it is made once and serves any number of plans and calls:
+ *
+ *     rank 0: glv_halo_unique_id(id);  hand the GLV_HALO_ID_BYTES bytes to every rank
+ *     all:    glv_halo_create(&halo, id, rank, world, device);   collective: returns when all joined
+ *             glv_halo_attach(plan, halo);                        (NULL detaches; the plan does not own it)
+ *             glv_shard_begin(...); glv_shard_exchange(plan, stream);
+ *             repeat n_iter times { glv_shard_step(...); glv_shard_exchange(plan, stream); }
+ *             glv_shard_end(...);
+ *             ... glv_halo_destroy(halo) when the stream has drained.
+ *
+ * glv_shard_exchange sends this shard's head blocks to rank - 1 and its tail blocks to rank + 1
+ * and receives theirs in place (the regions glv_shard_halo_views names), all four transfers in
+ * one RCCL group.  RCCL is loaded at run time (librccl.so.1; the copy the process already holds,
+ * if any); without it these calls return GLV_ERR_UNSUPPORTED.  Option "halo_loopback" = 1 is a
+ * test aid for a single rank: both neighbours are the rank itself, so each side receives what
+ * it sent.
+ */
+#define GLV_HALO_ID_BYTES 128
+typedef struct glv_halo glv_halo;
+int glv_halo_unique_id(void* id_out);
+int glv_halo_create(glv_halo** out, const void* id, int rank, int world, int device);
+int glv_halo_destroy(glv_halo* halo);
+int glv_halo_attach(glv_plan* plan, glv_halo* halo);
+int glv_shard_exchange(glv_plan* plan, void* stream);
+
+/*
  * Tuning and measurement hooks (no counterpart in the reference).
  *   glv_plan_set_option: "frames_per_run" (target frames one wavefront walks; 0 = automatic),
  *                        "run_target" (number of runs the automatic run table aims at; 0 = chosen

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-iteration cost of the halo swap at the long-form shard size (6 460 frames of a longer
+utterance, neighbours on both sides), one process on one GPU: no swap at all (timing floor, wrong
+result), the swap as four device copies (pack / unpack), and the swap issued by the library over
+RCCL with the rank as its own neighbour (send / recv of 2 x (n_fft - hop) floats each way per
+iteration, on the compute stream, no host wait).  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    from tts_amd.vocoder import GriffinLimPlan, HaloChain
+    per_rank = int(sys.argv[1]) if len(sys.argv) > 1 else 6460
+    n_fft, hop, n_iter = 1024, 256, 60
+    dev = torch.device("cuda:0")
+    f = n_fft // 2 + 1
+    s = torch.from_numpy((np.random.default_rng(1).standard_normal((per_rank, f)) ** 2).astype(np.float32)).to(dev)
+    plan = GriffinLimPlan(n_fft, hop, n_fft, 80, per_rank, 1, dev)
+    chain = HaloChain(HaloChain.unique_id(), 0, 1, dev)
+    plan.halo_attach(chain)
+    plan.set_option("halo_loopback", 1)
+
+    def copies():
+        a, b = plan.shard_halo_pack()
+        plan.shard_halo_unpack(a, b)
+
+    def timed(swap):
+        best = 1e9
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan.shard_begin(s, per_rank, 3 * per_rank, seed=3)
+            swap()
+            for _ in range(n_iter):
+                plan.shard_step(0.99)
+                swap()
+            plan.shard_end()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return round(1e3 * best / (n_iter + 1), 4)
+
+    out = {"frames_per_rank": per_rank, "n_iter": n_iter,
+           "ms_per_iteration_no_swap": timed(lambda: None),
+           "ms_per_iteration_device_copies": timed(copies),
+           "ms_per_iteration_library_rccl_loopback": timed(plan.shard_exchange)}
+    plan.halo_attach(None)
+    plan.close()
+    chain.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -951,3 +951,68 @@ def test_phase_drawn_inside_the_first_inverse_equals_stored_spectrum(voc, n_fft,
             assert float(y1.abs().max()) > 0
             assert torch.equal(y1, y0), (k, src)
     plan.close()
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 256)])
+def test_library_halo_exchange_over_rccl_to_itself(voc, n_fft, hop):
+    """The swap issued by the library (glv_halo_attach / glv_shard_exchange: RCCL send / recv on
+    the plan's stream).  One GPU allows one rank, so the rank is made its own neighbour on both
+    sides ("halo_loopback"): every side then receives what it sent, which the same shard gets
+    from glv_shard_halo_pack / glv_shard_halo_unpack with the packed buffers handed back.  Same
+    kernels, same data: the two waveforms must be identical - which checks the regions, the
+    sizes, the pairing of sends and receives and their ordering against the steps on the stream.
+    Also: exchanging without a communicator attached, and a shard with a neighbour on a side
+    where the rank has none, are refused."""
+    frames, t0, t1, n_iter = 160, 40, 110, 5
+    f = n_fft // 2 + 1
+    rng = np.random.default_rng(53)
+    s = dev((rng.standard_normal((t1 - t0, f)) ** 2).astype(np.float32))
+
+    def run(plan, swap):
+        plan.set_option("frames_per_run", 9)
+        plan.shard_begin(s, t0, frames, seed=11)
+        swap(plan)
+        for _ in range(n_iter):
+            plan.shard_step(0.99)
+            swap(plan)
+        y, n_begin = plan.shard_end()
+        return y.clone(), n_begin
+
+    def swap_by_copies(plan):
+        to_prev, to_next = plan.shard_halo_pack()
+        plan.shard_halo_unpack(to_prev, to_next)
+
+    ref_plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t1 - t0, 1)
+    y_ref, b_ref = run(ref_plan, swap_by_copies)
+    with pytest.raises(Exception):
+        ref_plan.shard_begin(s, t0, frames, seed=11)
+        ref_plan.shard_exchange()                         # not attached
+    ref_plan.close()
+
+    chain = voc.HaloChain(voc.HaloChain.unique_id(), 0, 1)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t1 - t0, 1)
+    plan.halo_attach(chain)
+    plan.shard_begin(s, t0, frames, seed=11)
+    with pytest.raises(Exception):
+        plan.shard_exchange()                             # rank 0 of 1 has no neighbours, the shard has two
+    plan.set_option("halo_loopback", 1)
+    y, b = run(plan, lambda p: p.shard_exchange())
+    # the same communicator serves a second plan
+    other = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t1 - t0, 1)
+    other.halo_attach(chain)
+    other.set_option("halo_loopback", 1)
+    y2, _ = run(other, lambda p: p.shard_exchange())
+    torch.cuda.synchronize()
+    assert b == b_ref and y.shape == y_ref.shape and float(y.abs().max()) > 0
+    assert torch.equal(y, y_ref) and torch.equal(y2, y_ref)
+    plan.halo_attach(None)
+    with pytest.raises(Exception):
+        plan.shard_begin(s, t0, frames, seed=11)
+        plan.shard_exchange()                             # detached
+    with pytest.raises(Exception):
+        voc.HaloChain(b"short", 0, 1)
+    with pytest.raises(Exception):
+        voc.HaloChain(voc.HaloChain.unique_id(), 1, 1)    # rank outside [0, world)
+    other.close()
+    plan.close()
+    chain.close()

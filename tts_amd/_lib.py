@@ -63,6 +63,12 @@ SIGNATURES = {
     "glv_shard_output_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                               ctypes.POINTER(ctypes.c_int64)]),
     "glv_shard_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "glv_halo_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "glv_halo_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int]),
+    "glv_halo_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "glv_halo_attach": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "glv_shard_exchange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "glv_melspectrogram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p, c_int_p,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_power_to_db": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,

@@ -1,6 +1,7 @@
 // libglvoc: the plan (tables, workspace, run bookkeeping, graph cache) and the C ABI declared in
 // include/glvoc.h.  The kernels are in kernels.h, the per-wavefront engine in engine.h and
 // wave_fft.h.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -152,6 +153,10 @@ struct glv_plan {
     uint64_t graph_clock = 0;
     // time-shard state (glv_shard_*): frames [t0, t1) of a T-frame utterance live here
     bool shard_active = false;
+    // the in-library halo exchange (glv_halo_attach): this process's place in the chain of
+    // shards; null = the caller moves the halos
+    glv_halo* halo = nullptr;  // not owned
+    int halo_loopback = 0;     // test aid: both neighbours are this rank itself
     int shard_t0 = 0, shard_t1 = 0, shard_T = 0, shard_cur = 0, shard_k = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -672,6 +677,8 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->nnls_fused = value != 0;
     } else if (!strcmp(name, "zero_skip")) {
         p->zero_skip = value != 0;
+    } else if (!strcmp(name, "halo_loopback")) {
+        p->halo_loopback = value != 0;
     } else if (!strcmp(name, "fuse_draw")) {
         p->fuse_draw = value != 0;
     } else if (!strcmp(name, "single_frame")) {
@@ -1395,6 +1402,152 @@ extern "C" int glv_shard_end(glv_plan* p, float* y_dev, void* stream) {
         HIP_TRY(hipGetLastError());
     }
     p->shard_active = false;
+    return GLV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Halo exchange inside the library: RCCL point-to-point on the caller's stream.
+// RCCL is looked up at run time (the library has no link-time dependency on it): a process
+// that already holds a copy (PyTorch ships one) gets that one, any other the system's.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RcclId {
+    char internal[128];  // ncclUniqueId
+};
+}  // namespace
+struct glv_halo {
+    void* comm;  // ncclComm_t
+    int rank, world, device;
+};
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kRcclFloat32 = 7;  // ncclFloat32
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+        api.GetUniqueId = reinterpret_cast<int (*)(RcclId*)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclId, int)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<int (*)(void*)>(sym("ncclCommDestroy"));
+        api.Send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, hipStream_t)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, hipStream_t)>(sym("ncclRecv"));
+        api.GroupStart = reinterpret_cast<int (*)()>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<int (*)()>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv &&
+                 api.GroupStart && api.GroupEnd && api.GetErrorString;
+    });
+    return api.ok ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                    \
+    do {                                                                                       \
+        const int r_ = (expr);                                                                 \
+        if (r_ != 0) return fail(GLV_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" int glv_halo_unique_id(void* id_out) {
+    if (!id_out) return fail(GLV_ERR_INVALID, "null argument");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+    RcclId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    memcpy(id_out, id.internal, GLV_HALO_ID_BYTES);
+    return GLV_OK;
+}
+
+extern "C" int glv_halo_create(glv_halo** out, const void* id, int rank, int world, int device) {
+    if (!out || !id) return fail(GLV_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(GLV_ERR_INVALID, "rank %d outside [0, %d)", rank, world);
+    RcclApi* api = rccl_api();
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(GLV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    RcclId uid;
+    memcpy(uid.internal, id, GLV_HALO_ID_BYTES);
+    void* comm = nullptr;
+    RCCL_TRY(api, api->CommInitRank(&comm, world, uid, rank));
+    *out = new glv_halo{comm, rank, world, device};
+    return GLV_OK;
+}
+
+extern "C" int glv_halo_destroy(glv_halo* h) {
+    if (!h) return GLV_OK;
+    RcclApi* api = rccl_api();
+    DeviceGuard guard(h->device);
+    void* comm = h->comm;
+    delete h;
+    if (api && comm) RCCL_TRY(api, api->CommDestroy(comm));
+    return GLV_OK;
+}
+
+extern "C" int glv_halo_attach(glv_plan* p, glv_halo* h) {
+    if (!p) return fail(GLV_ERR_INVALID, "null plan");
+    if (h && h->device != p->device)
+        return fail(GLV_ERR_INVALID, "the communicator lives on device %d, the plan on %d", h->device, p->device);
+    p->halo = h;
+    return GLV_OK;
+}
+
+extern "C" int glv_shard_exchange(glv_plan* p, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (!p->halo) return fail(GLV_ERR_STATE, "glv_halo_attach has not been called");
+    const glv_halo* h = p->halo;
+    RcclApi* api = rccl_api();
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded");
+    float *send_prev, *send_next, *recv_prev, *recv_next;
+    rc = glv_shard_halo_views(p, &send_prev, &send_next, &recv_prev, &recv_next);
+    if (rc != GLV_OK) return rc;
+    // the shard before this one is the rank before this one, and likewise after
+    const int prev = p->halo_loopback ? h->rank : h->rank - 1;
+    const int next = p->halo_loopback ? h->rank : h->rank + 1;
+    if (send_prev && prev < 0) return fail(GLV_ERR_STATE, "shard starts at frame %d but rank 0 has no rank before it", p->shard_t0);
+    if (send_next && next >= h->world)
+        return fail(GLV_ERR_STATE, "shard ends at frame %d of %d but rank %d is the last", p->shard_t1, p->shard_T,
+                    h->rank);
+    if (!send_prev && !send_next) return GLV_OK;
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)(p->R - 1) * p->hop;
+    // one group: all four transfers progress together, so neighbours that post them in the
+    // same order cannot wait on each other
+    RCCL_TRY(api, api->GroupStart());
+    int e = 0;
+    if (send_prev) {
+        e = api->Send(send_prev, n, kRcclFloat32, prev, h->comm, st);
+        if (!e) e = api->Recv(recv_prev, n, kRcclFloat32, prev, h->comm, st);
+    }
+    if (!e && send_next) {
+        e = api->Send(send_next, n, kRcclFloat32, next, h->comm, st);
+        if (!e) e = api->Recv(recv_next, n, kRcclFloat32, next, h->comm, st);
+    }
+    const int eg = api->GroupEnd();
+    if (e) return fail(GLV_ERR_HIP, "ncclSend / ncclRecv failed: %s", api->GetErrorString(e));
+    if (eg) return fail(GLV_ERR_HIP, "ncclGroupEnd failed: %s", api->GetErrorString(eg));
     return GLV_OK;
 }
 

@@ -160,9 +160,25 @@ def _all_reduce_max(x, group):
     return host.to(x.device)
 
 
+_HALO_CHAINS = {}
+
+
+def _halo_chain(group, rank, world, device):
+    """The library-side communicator of `group` on this device: made on first use (collective:
+    rank 0's id travels through the group), then kept for the life of the process."""
+    from .vocoder import HaloChain
+    key = (id(group) if group is not None else None, world, rank, str(device))
+    chain = _HALO_CHAINS.get(key)
+    if chain is None:
+        box = [HaloChain.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        chain = _HALO_CHAINS[key] = HaloChain(box[0], rank, world, device)
+    return chain
+
+
 def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length=256, win_length=None,
                              n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, seed=0, group=None,
-                             device=None, normalize=True):
+                             device=None, normalize=True, transport=None):
     """Long-form synthesis of ONE utterance sharded along time over the ranks of `group`
     (for example a 10-minute mel over 8 GPUs).
 
@@ -170,6 +186,12 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
     `split_frames(T, world)[r]`, inverts and iterates only those, and swaps n_fft - hop
     samples with each neighbour once per iteration (61 swaps for 60 iterations).  The peak
     for the final normalisation is one all-reduce(MAX) of one float.
+
+    `transport`: "library" - the swap is RCCL send / recv issued by libglvoc itself on the
+    compute stream (glv_halo_create / glv_shard_exchange; the communicator is made once per
+    group from an id that rank 0 broadcasts through it); "torch" - torch.distributed point-to-point on
+    views of the plan's workspace.  Default: "library" when the group's backend is RCCL and
+    every rank has a GPU of its own, else "torch".
 
     Returns (y_local, n_begin): a float32 device tensor with this rank's samples
     [n_begin, n_begin + len(y_local)) of the waveform.
@@ -189,8 +211,17 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
     plan.shard_begin(s_local, t0, frames, seed=seed)
 
     on_device = dist.get_backend(group) == "nccl"
+    if transport is None:
+        transport = "library" if on_device else "torch"
+    if transport not in ("library", "torch"):
+        raise ValueError("transport must be 'library' or 'torch'")
+    if transport == "library":
+        plan.halo_attach(_halo_chain(group, rank, world, plan.device))
 
     def swap():
+        if transport == "library":
+            plan.shard_exchange()
+            return
         # The halos are sent from and received into the plan's workspace where they lie: no
         # packing.  Under RCCL the transfers are ordered on the device after the step that wrote
         # them and before the step that reads them (wait() makes the compute stream wait for the
@@ -205,6 +236,8 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
         plan.shard_step(momentum)
         swap()
     y, n_begin = plan.shard_end()
+    if transport == "library":
+        plan.halo_attach(None)
     if normalize and y.numel():
         row = y.unsqueeze(0)
         peak = _all_reduce_max(plan.peak_reduce(row), group)

@@ -14,6 +14,7 @@ device memory and the stream.
 from __future__ import annotations
 
 import ctypes
+import sys
 import threading
 
 import numpy as np
@@ -22,7 +23,7 @@ import torch
 from . import _lib
 from .filters import inverse_mel_basis, mel_basis_and_step
 
-__all__ = ["GriffinLimPlan", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch", "mel_to_audio",
+__all__ = ["GriffinLimPlan", "HaloChain", "get_plan", "mel_to_audio_griffin_lim", "griffin_lim_batch", "mel_to_audio",
            "audio_to_mel_db"]
 
 
@@ -44,6 +45,42 @@ class _DeviceFloats:
 
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class HaloChain:
+    """This process's place in a chain of time shards: an RCCL communicator inside libglvoc
+    (glv_halo_create).  `unique_id()` on one rank, the bytes handed to all, then every rank
+    constructs its HaloChain (collective).  Serves any number of plans and calls."""
+
+    def __init__(self, unique_id, rank, world, device=None):
+        self.lib = _lib.load()
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes HaloChain.unique_id() returned")
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.glv_halo_create(ctypes.byref(handle), ctypes.c_char_p(bytes(unique_id)), int(rank),
+                                            int(world), int(device.index or 0)))
+        self._handle, self.rank, self.world, self.device = handle, int(rank), int(world), device
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().glv_halo_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self._handle is not None:
+            self.lib.glv_halo_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        # at interpreter shutdown the runtimes underneath may be gone already: leave it to the OS
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GriffinLimPlan:
@@ -321,6 +358,17 @@ class GriffinLimPlan:
                 cache[p.value] = torch.as_tensor(_DeviceFloats(p.value, n), device=self.device)
             out.append(cache[p.value])
         return tuple(out)
+
+    # -- halo exchange done by the library (RCCL on the plan's stream) ----------
+    def halo_attach(self, halo):
+        """Points the plan at a HaloChain (None detaches); the chain must outlive its use."""
+        handle = None if halo is None else halo._handle
+        _lib.check(self.lib.glv_halo_attach(self._handle, handle))
+        self._halo_chain = halo
+
+    def shard_exchange(self):
+        """Swaps the halos of the newest generation with ranks -1 / +1 on the plan's stream."""
+        _lib.check(self.lib.glv_shard_exchange(self._handle, _stream_ptr(self.device)))
 
     def shard_end(self):
         """Returns (y_local, n_begin): this shard's samples [n_begin, n_begin + len(y_local))
