@@ -278,6 +278,7 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
  *             glv_halo_attach(plan, halo);                        (NULL detaches; the plan does not own it)
  *             glv_shard_begin(...); glv_shard_exchange(plan, stream);
  *             repeat n_iter times { glv_shard_step(...); glv_shard_exchange(plan, stream); }
+ *                                                 (or glv_shard_run for the three lines above)
  *             glv_shard_end(...);
  *             ... glv_halo_destroy(halo) when the stream has drained.
  *
@@ -295,6 +296,9 @@ int glv_halo_create(glv_halo** out, const void* id, int rank, int world, int dev
 int glv_halo_destroy(glv_halo* halo);
 int glv_halo_attach(glv_plan* plan, glv_halo* halo);
 int glv_shard_exchange(glv_plan* plan, void* stream);
+/* glv_shard_exchange, then n_iter times { glv_shard_step; glv_shard_exchange }: the whole loop
+ * after glv_shard_begin enqueued by one call. */
+int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
 
 /*
  * Tuning and measurement hooks (no counterpart in the reference).

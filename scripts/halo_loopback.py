@@ -48,7 +48,20 @@ def main():
             best = min(best, time.perf_counter() - t0)
         return round(1e3 * best / (n_iter + 1), 4)
 
+    def one_call():
+        best = 1e9
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan.shard_begin(s, per_rank, 3 * per_rank, seed=3)
+            plan.shard_run(n_iter, 0.99)
+            plan.shard_end()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return round(1e3 * best / (n_iter + 1), 4)
+
     out = {"frames_per_rank": per_rank, "n_iter": n_iter,
+           "ms_per_iteration_library_rccl_loopback_one_call": one_call(),
            "ms_per_iteration_no_swap": timed(lambda: None),
            "ms_per_iteration_device_copies": timed(copies),
            "ms_per_iteration_library_rccl_loopback": timed(plan.shard_exchange)}

@@ -69,6 +69,7 @@ SIGNATURES = {
     "glv_halo_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "glv_halo_attach": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "glv_shard_exchange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "glv_shard_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "glv_melspectrogram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c_int_p, c_int_p,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "glv_power_to_db": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int_p, ctypes.c_int,

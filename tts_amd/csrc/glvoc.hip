@@ -1551,6 +1551,21 @@ extern "C" int glv_shard_exchange(glv_plan* p, void* stream) {
     return GLV_OK;
 }
 
+extern "C" int glv_shard_run(glv_plan* p, int n_iter, float momentum, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (n_iter < 0) return fail(GLV_ERR_INVALID, "n_iter must be >= 0");
+    if (!p->halo) return fail(GLV_ERR_STATE, "glv_halo_attach has not been called");
+    // the swap that completes the initial inverse transform, then step and swap n_iter times:
+    // everything is enqueued on the one stream, the host never waits
+    rc = glv_shard_exchange(p, stream);
+    for (int k = 0; k < n_iter && rc == GLV_OK; ++k) {
+        rc = glv_shard_step(p, momentum, stream);
+        if (rc == GLV_OK) rc = glv_shard_exchange(p, stream);
+    }
+    return rc;
+}
+
 namespace {
 
 int peak_prepare(glv_plan* p, const int* n_samples_host, int batch, int64_t y_stride, hipStream_t st,

@@ -219,9 +219,6 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
         plan.halo_attach(_halo_chain(group, rank, world, plan.device))
 
     def swap():
-        if transport == "library":
-            plan.shard_exchange()
-            return
         # The halos are sent from and received into the plan's workspace where they lie: no
         # packing.  Under RCCL the transfers are ordered on the device after the step that wrote
         # them and before the step that reads them (wait() makes the compute stream wait for the
@@ -231,10 +228,13 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
             torch.cuda.current_stream(plan.device).synchronize()
         exchange_halos(to_prev, to_next, from_prev, from_next, group=group)
 
-    swap()
-    for _ in range(n_iter):
-        plan.shard_step(momentum)
+    if transport == "library":
+        plan.shard_run(n_iter, momentum)
+    else:
         swap()
+        for _ in range(n_iter):
+            plan.shard_step(momentum)
+            swap()
     y, n_begin = plan.shard_end()
     if transport == "library":
         plan.halo_attach(None)

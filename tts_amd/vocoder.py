@@ -370,6 +370,11 @@ class GriffinLimPlan:
         """Swaps the halos of the newest generation with ranks -1 / +1 on the plan's stream."""
         _lib.check(self.lib.glv_shard_exchange(self._handle, _stream_ptr(self.device)))
 
+    def shard_run(self, n_iter, momentum=0.99):
+        """The swap after shard_begin, then n_iter steps each followed by its swap, enqueued by
+        one library call (needs halo_attach)."""
+        _lib.check(self.lib.glv_shard_run(self._handle, int(n_iter), float(momentum), _stream_ptr(self.device)))
+
     def shard_end(self):
         """Returns (y_local, n_begin): this shard's samples [n_begin, n_begin + len(y_local))
         of the whole (un-normalised) waveform."""
