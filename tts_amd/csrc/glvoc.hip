@@ -280,7 +280,7 @@ hipError_t launch_mel_native_t(const glv_plan* p, const ElemArgs& ea, const floa
     const size_t lds = (size_t)(32 * (p->Mp + 1) + 32 * kMelTileStride + 32) * sizeof(float);
     hipLaunchKernelGGL((mel_native_kernel<A>), dim3((unsigned)((rows + 31) / 32)), dim3(64 * kMelWaves), lds, st, ea,
                        mel_db, p->d_pinv_t, p->n_mels, p->Mp, p->Fp, mean, std_, phase, seed, inv_n, p->d_S,
-                       spec, peak_bits);
+                       spec, peak_bits, (int)std::min<int64_t>((int64_t)p->kmax_bin + 1, p->F));
     return hipGetLastError();
 }
 

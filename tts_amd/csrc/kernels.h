@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
                                                          const float* __restrict__ Wt, int M, int Mp, int Fp,
                                                          float mean, float std_, const cf* phase_nat,
                                                          uint64_t seed, float inv_n, float* S_native,
-                                                         cf* spec, unsigned* peak_bits) {
+                                                         cf* spec, unsigned* peak_bits, int live_bins) {
     extern __shared__ float mel_smem[];
     // the per-utterance maxima the finalising kernel gathers start at zero (a memset of its
     // own would cost a gap in the stream)
@@ -827,8 +827,17 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
     };
     // frame (0..31) of accumulator register `reg` in this lane
     auto acc_frame = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); };
+    // bins from live_bins on have all-zero rows in the inverse basis: their products are exactly
+    // zero and are not computed
+    auto product_or_zero = [&](int col0) {
+        if (col0 < live_bins) return product(col0);
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        return z;
+    };
     if (wave == kMelWaves - 1) {
-        const f32x16 acc = product(P);
+        const f32x16 acc = product_or_zero(P);
         if ((lane & 31) == 0) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) nyq[acc_frame(reg)] = acc[reg];
@@ -841,7 +850,7 @@ __global__ __launch_bounds__(64 * kMelWaves) void mel_native_kernel(ElemArgs ea,
     const int low = (lane >> 3) + 8 * (lane & 7);  // this lane's bin modulo 64 on the frequency side
     for (int h = 0; h < A; ++h) {
         for (int c = wave; c < 16; c += kMelWaves) {
-            const f32x16 acc = product(512 * h + 32 * c);
+            const f32x16 acc = product_or_zero(512 * h + 32 * c);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) tile[acc_frame(reg) * kMelTileStride + 32 * c + (lane & 31)] = acc[reg];
         }
