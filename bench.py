@@ -8,10 +8,10 @@ Griffin-Lim (momentum 0.99, fp32) on synthetic LJSpeech-shaped 80-mel utterances
 A step is one pass of the whole hot path over one batch already resident in HBM:
 mel inversion -> 60 Griffin-Lim iterations -> peak normalisation.
 
---config 1 (default; BASELINE configs[1]): a batch of 64 utterances per GPU.  For N > 1 the
+--config 1 (default; BASELINE.json configs[1]): a batch of 64 utterances per GPU.  For N > 1 the
   driver starts one process per GPU with torch.distributed.run; every rank processes its own
   batch (weak scaling, no data-path collective) and the slowest rank's time counts.
---config 3 (BASELINE configs[2]): 4096 utterances in all, dealt to the N ranks by length
+--config 3 (BASELINE.json configs[2]): 4096 utterances in all, dealt to the N ranks by length
   (tts_amd.distributed.shard_by_length); a step is every rank's shard plus ONE gather of the
   waveforms to rank 0 on the device (RCCL), inside the timed region; strong scaling.
 Rank 0 prints one JSON line.

@@ -269,7 +269,7 @@ int glv_shard_end(glv_plan* plan, float* y_dev, void* stream);
 /*
  * The swap done by the library itself: RCCL point-to-point on the caller's stream, between
  * glv_shard_begin / glv_shard_step and the next step, with no host wait (the reference has no
- * counterpart; BASELINE's long-form configuration names this exchange).  One process per GPU,
+ * counterpart: it synthesises one utterance on one CPU thread).  One process per GPU,
  * rank r holds shard r of `world` consecutive shards.  A glv_halo is this process's place in
  * that chain (an RCCL communicator); it is made once and serves any number of plans and calls:
  *

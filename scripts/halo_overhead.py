@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-iteration cost of the time-sharded Griffin-Lim at the long-form shard size (BASELINE
+"""Per-iteration cost of the time-sharded Griffin-Lim at the long-form shard size (BASELINE.json
 configs[3]: 51 680 frames over 8 GPUs = 6 460 frames per rank), on the hardware at hand:
 
     python -m torch.distributed.run --nproc-per-node 1 scripts/halo_overhead.py nccl

@@ -302,7 +302,7 @@ def test_full_size_batch_properties(voc, O):
 
 
 def test_configs2_batch_of_4096(voc, O):
-    """BASELINE configs[2] on one GPU: 4096 synthetic utterances x 430 frames, 60 iterations, one
+    """BASELINE.json configs[2] on one GPU: 4096 synthetic utterances x 430 frames, 60 iterations, one
     call.  Size-independent properties over the whole batch, and sampled rows against the oracle:
     every sampled utterance is re-synthesised alone with an explicit phase by the library and
     by the oracle (1e-3), and alone with its identity on the device-drawn phase, which must give
