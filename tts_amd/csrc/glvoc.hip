@@ -1135,6 +1135,14 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         hipLaunchKernelGGL(finalize_parts_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
                            p->d_parts + (size_t)(n_iter & 1) * p->R * p->parts_stride, p->parts_stride, p->d_iwss,
                            p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev, y_stride, peak_bits);
+    } else if (y_stride % 4 == 0 && reinterpret_cast<uintptr_t>(y_dev) % 16 == 0) {
+        int hop_shift = 0;
+        while ((1 << hop_shift) < p->hop) ++hop_shift;
+        const unsigned blocks4 = peak_bits ? std::min<unsigned>(grid_for(y_stride / 4, 256), std::max(32, 2048 / batch))
+                                           : grid_for(y_stride / 4, 256);
+        hipLaunchKernelGGL(finalize4_kernel, dim3(blocks4, batch), dim3(256), 0, st, ea, p->d_ym[last], p->d_yt[last],
+                           p->d_flags, p->blocks, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev,
+                           y_stride, hop_shift, peak_bits);
     } else {
         hipLaunchKernelGGL(finalize_kernel, dim3(fin_blocks, batch), dim3(256), 0, st, ea,
                            p->d_ym[last], p->d_yt[last], p->d_flags, p->blocks, p->d_w2, p->d_iwss, p->d_iwss_head,

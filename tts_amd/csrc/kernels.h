@@ -396,6 +396,51 @@ __global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float*
     }
 }
 
+// finalize_kernel for whole rows, four consecutive samples per thread (16-byte accesses; the hop
+// is a power of two and a multiple of 4, so the four share their block and the index arithmetic
+// is shifts).  The same operations per sample, hence the same bits.  Needs out and out_stride
+// aligned to four floats.
+__global__ __launch_bounds__(256) void finalize4_kernel(ElemArgs ea, const float* y_main, const float* y_tail,
+                                                        const unsigned char* tail_flag, int blocks_stride,
+                                                        const float* iwss, const float* iwss_head,
+                                                        const float* iwss_tail, const float* iwss_small,
+                                                        float* out, int64_t out_stride, int hop_shift,
+                                                        unsigned* peak_bits) {
+    __shared__ float wave_max[4];
+    const int b = blockIdx.y;
+    const LayoutArgs& L = ea.L;
+    const int T = L.n_frames[b];
+    const int64_t len = (int64_t)L.hop * (T - 1);
+    float m = 0.f;
+    for (int64_t n = 4 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x); n < out_stride;
+         n += 4 * (int64_t)gridDim.x * blockDim.x) {
+        f4 val = f4{0.f, 0.f, 0.f, 0.f};
+        if (n < len) {
+            const int64_t p = n + L.n_fft / 2;
+            const int j = (int)(p >> hop_shift), s = (int)(p & (L.hop - 1));
+            const int64_t at = (int64_t)b * L.y_utt_stride + p;
+            if (j < T) val = *reinterpret_cast<const f4*>(y_main + at);
+            if (tail_flag[(int64_t)b * blocks_stride + j]) {
+                const f4 t = *reinterpret_cast<const f4*>(y_tail + at);
+                val = f4{val.x + t.x, val.y + t.y, val.z + t.z, val.w + t.w};
+            }
+            const f4 iw = *reinterpret_cast<const f4*>(iwss_row(iwss, iwss_head, iwss_tail, iwss_small, L.hop, L.R, T, j) + s);
+            val = f4{val.x * iw.x, val.y * iw.y, val.z * iw.z, val.w * iw.w};
+        }
+        *reinterpret_cast<f4*>(out + (int64_t)b * out_stride + n) = val;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(val.x), fabsf(val.y))), fmaxf(fabsf(val.z), fabsf(val.w)));
+    }
+    if (!peak_bits) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(&peak_bits[b], __float_as_uint(m));
+    }
+}
+
 // finalize_kernel for the one-frame-per-wave modes: the sample is the sum of R partial buffers
 __global__ __launch_bounds__(256) void finalize_parts_kernel(ElemArgs ea, const float* parts, int64_t part_stride,
                                                              const float* iwss, const float* iwss_head,
