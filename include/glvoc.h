@@ -326,6 +326,11 @@ int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
  *                        "fuse_draw" (1/0, default 1: with no phase0 and "linear" on, the first inverse
  *                        transform draws the initial phase itself and S*phase is never stored;
  *                        0 = the set-up kernel stores it; same bits either way),
+ *                        "deposit" (1/0, default 1: n_fft 1024, "linear" on, no convergence curve - where two
+ *                        consecutive runs of an utterance are waves of one workgroup, the later one
+ *                        hands its partial sums of the boundary blocks over through LDS and the
+ *                        earlier one writes them complete, instead of both writing halves that
+ *                        every reader adds; same bits either way),
  *                        "nnls_fused" (1/0, default 1: all steps of glv_mel_invert_nnls in one launch
  *                        with the solution resident in registers; 0 = two launches per step),
  *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue

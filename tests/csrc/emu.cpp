@@ -25,9 +25,25 @@ void emu_launch(const IterArgs& a) {
     using G = Geo<A>;
     std::vector<cf> b0(G::XBUF), b1(G::XBUF);
     std::vector<Eng> e(64);
-    for (int ri = 0; ri < a.n_runs; ++ri) {
+    // Run boundaries completed by the producer (IterArgs::deposit): on the device the later run of
+    // a workgroup deposits its head sums in LDS early and the earlier run picks them up at its
+    // end.  The runs of a launch are independent of each other, so here they are simply taken in
+    // descending order: when a run ends, the deposit of the run after it is already there.
+    constexpr bool kCanDeposit = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ISTFT) && !SC && A == 1;
+    const bool deposit = kCanDeposit && a.deposit != 0;
+    std::vector<cf> dep_mine(Eng::kShareFloats / 2 + 1), dep_next(Eng::kShareFloats / 2 + 1);
+    for (int ri = a.n_runs - 1; ri >= 0; --ri) {
         const RunDesc run = a.runs[ri];
         for (int l = 0; l < 64; ++l) e[l].init(a, a.tables, l, run);
+        std::swap(dep_mine, dep_next);  // what the run after this one deposited
+        if (deposit) {
+            const bool out = (ri % 4) != 0 && a.runs[ri - 1].utt == run.utt;
+            const bool in = (ri % 4) != 3 && ri + 1 < a.n_runs && a.runs[ri + 1].utt == run.utt;
+            for (int l = 0; l < 64; ++l) {
+                e[l].deposit_out = out ? dep_mine.data() : nullptr;
+                e[l].deposit_in = in ? dep_next.data() : nullptr;
+            }
+        }
         if (MODE == MODE_ITER1 || MODE == MODE_ISTFT1) {
             // one frame per wave: no sliding window, no running sum
             const int t = run.t_begin;
@@ -287,7 +303,12 @@ struct Emu {
     }
 
     int griffinlim(const float* S, const float* phase0, uint64_t seed, int n_iter, float momentum,
-                   float* y, int64_t y_stride, float* sc, bool recompute, int linear = 0) {
+                   float* y, int64_t y_stride, float* sc, bool recompute, int linear = 0, bool deposit = false) {
+        // deposit: run boundaries inside groups of 4 runs completed by the producer, where the
+        // device kernels can do that (n_fft 1024, time-domain momentum, no convergence curve)
+        deposit = deposit && A == 1 && linear != 0 && sc == nullptr;
+        flags = build_tail_flags(runs, batch, blocks, R, deposit ? 4 : 0);
+        a.deposit = deposit ? 1 : 0;
         // linear: 1 = momentum in the time domain (magnitudes in pair order), 2 = the same with
         // the upper quarter of every lane's bins known to be zero
         L.s_pair_nzh = linear == 1 ? 4 * A : (linear == 2 ? 2 * A : 0);
@@ -408,13 +429,16 @@ int emu_griffinlim(int n_fft, int hop, int win_length, const float* S, const flo
                    float momentum, int frames_per_run, float* y, int64_t y_stride, float* sc, int recompute) {
     // recompute: 0 = run-based iteration, 1 = its recompute-the-previous-spectrum variant,
     //            2 = one frame per wave, 3 = momentum in the time domain, 4 = the same with the
-    //            magnitudes of the upper quarter of every lane's registers known to be zero
+    //            magnitudes of the upper quarter of every lane's registers known to be zero,
+    //            5 / 6 = 3 / 4 with the run boundaries inside a workgroup completed by the producer
     return dispatch(n_fft, hop, [&](auto* tag) {
         using E = std::remove_pointer_t<decltype(tag)>;
         E e(Shape{n_fft, hop, win_length}, n_frames, batch, frames_stride, frames_per_run);
         if (recompute == 2) return e.griffinlim_single(S, phase0, seed, n_iter, momentum, y, y_stride, sc);
         if (recompute == 3) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 1);
         if (recompute == 4) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 2);
+        if (recompute == 5) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 1, true);
+        if (recompute == 6) return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, false, 2, true);
         return e.griffinlim(S, phase0, seed, n_iter, momentum, y, y_stride, sc, recompute != 0);
     });
 }

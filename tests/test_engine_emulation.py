@@ -221,6 +221,40 @@ def test_time_domain_momentum_is_the_same_iteration(emu, n_fft, hop, win, frames
     assert np.array_equal(y, y2)
 
 
+@pytest.mark.parametrize("n_fft,hop,win,lens,fpr", [(1024, 256, 1024, [40, 23, 7, 64], 3), (1024, 256, 1024, [90], 5),
+                                                    (1024, 256, 1024, [33, 3, 50], 9), (1024, 128, 1024, [60, 31], 7),
+                                                    (1024, 512, 1024, [30, 12], 1), (1024, 256, 800, [45, 17], 4),
+                                                    (2048, 256, 2048, [40, 20], 7)])
+def test_run_boundaries_completed_by_the_producer(emu, n_fft, hop, win, lens, fpr):
+    """Where two consecutive runs of an utterance are waves of one workgroup, the later run can
+    hand its head sums to the earlier one, which writes the boundary blocks complete (modes 5 and
+    6) instead of both writing halves that every reader adds (modes 3 and 4).  head + tail either
+    way: the waveforms must be identical bit for bit - with all bins kept and with the upper
+    quarter left out, for batches whose runs cross workgroup and utterance boundaries, for 0 and
+    several iterations - and match the oracle.  (n_fft 2048 has no such kernels: the mode is
+    accepted and changes nothing.)"""
+    rng = np.random.default_rng(7 + len(lens) + fpr)
+    f = n_fft // 2 + 1
+    t_max = max(lens)
+    s = np.zeros((len(lens), t_max, f), np.float32)
+    ph = np.zeros((len(lens), t_max, f, 2), np.float32)
+    for b, t in enumerate(lens):
+        s[b, :t] = rng.standard_normal((t, f)) ** 2
+        ang = 2 * np.pi * rng.random((t, f))
+        ph[b, :t, :, 0], ph[b, :t, :, 1] = np.cos(ang), np.sin(ang)
+    s_quarter = s.copy()
+    s_quarter[:, :, (3 * (n_fft // 2)) // 4:] = 0.0          # what mode 4 / 6 may assume
+    for k in (0, 1, 4):
+        for two_halves, by_producer, mags in ((3, 5, s), (4, 6, s_quarter)):
+            y_a, _ = emu_griffinlim(emu, mags, ph, lens, n_fft, hop, win, k, fpr, recompute=two_halves, want_sc=False)
+            y_b, _ = emu_griffinlim(emu, mags, ph, lens, n_fft, hop, win, k, fpr, recompute=by_producer, want_sc=False)
+            assert np.array_equal(y_a, y_b), (k, by_producer)
+    for b, t in enumerate(lens):                             # y_b: mode 6, 4 iterations
+        ref = O.griffinlim(np.ascontiguousarray(s_quarter[b, :t].T), n_iter=4, hop_length=hop, win_length=win,
+                           init_phase=(ph[b, :t, :, 0] + 1j * ph[b, :t, :, 1]).T.astype(np.complex64))
+        assert rel_l2(y_b[b, :hop * (t - 1)], ref) < 1e-5
+
+
 def test_time_domain_momentum_drift_on_the_fixture(emu, lj001):
     """Same bound as the spectral-domain form: 16 iterations on 430 frames of the reference's mel
     stay two orders below the 1e-3 parity bound."""

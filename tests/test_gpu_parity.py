@@ -1019,3 +1019,44 @@ def test_library_halo_exchange_over_rccl_to_itself(voc, n_fft, hop):
     other.close()
     plan.close()
     chain.close()
+
+
+@pytest.mark.parametrize("n_fft,hop,lens,fpr", [(1024, 256, [64, 40, 21, 2, 9], 0), (1024, 256, [150, 33], 5),
+                                                (1024, 128, [50, 12, 64], 9), (1024, 512, [40, 17], 0),
+                                                (2048, 256, [48, 30], 0)])
+def test_run_boundaries_completed_by_the_producer(voc, n_fft, hop, lens, fpr):
+    """Option "deposit": where consecutive runs of an utterance are waves of one workgroup the later
+    run hands its head sums over through LDS and the earlier one writes the boundary blocks
+    complete, instead of both writing halves that every reader adds.  The same additions in the
+    same order: waveforms must be identical bit for bit with the option on and off - from mel
+    input and from caller magnitudes, with explicit and device-drawn phases, after 0 and several
+    iterations - and the convergence curve (whose kernels keep the two-halves form) must come with
+    the same waveform.  (n_fft 2048 has no such kernels: the option changes nothing.)"""
+    f = n_fft // 2 + 1
+    t_max, b = max(lens), len(lens)
+    rng = np.random.default_rng(59)
+    mel = np.stack([np.pad(synthetic_mel(600 + i, t), ((0, t_max - t), (0, 0))) for i, t in enumerate(lens)])
+    s = np.zeros((b, t_max, f), np.float32)
+    p0 = np.zeros((b, t_max, f, 2), np.float32)
+    for i, t in enumerate(lens):
+        s[i, :t] = rng.standard_normal((t, f)) ** 2
+        ang = 2 * np.pi * rng.random((t, f))
+        p0[i, :t, :, 0], p0[i, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t_max, b)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    plan.set_option("single_frame", 0)
+    plan.set_option("frames_per_run", fpr)
+    got = {}
+    for dep in (1, 0):
+        plan.set_option("deposit", dep)
+        for k in (0, 1, 6):
+            got[dep, k, "mel"] = plan.mel_to_audio(dev(mel), MEAN, STD, lens, seed=3, n_iter=k).clone()
+            got[dep, k, "s"] = plan.griffinlim(dev(s), lens, phase0=dev(p0), n_iter=k).clone()
+        y_sc, sc = plan.griffinlim(dev(s), lens, phase0=dev(p0), n_iter=6, return_sc=True)
+        got[dep, 6, "sc"] = y_sc.clone()
+    for k in (0, 1, 6):
+        for src in ("mel", "s"):
+            assert float(got[1, k, src].abs().max()) > 0
+            assert torch.equal(got[1, k, src], got[0, k, src]), (k, src)
+    assert torch.equal(got[1, 6, "sc"], got[1, 6, "s"]) and torch.equal(got[0, 6, "sc"], got[0, 6, "s"])
+    plan.close()

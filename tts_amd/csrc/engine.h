@@ -124,6 +124,9 @@ struct IterArgs {
     float inv_n;              // 1 / n_fft
     int has_prev;             // 0 on the first iteration (no momentum term)
     int raw_in;               // y_in holds the padded signal itself (glv_stft)
+    int deposit;              // 1: run boundaries inside a workgroup are completed by the producer
+                              //    (Engine::deposit_out / deposit_in); every generation of the call
+                              //    and the tail flags follow the same convention
     // MODE_ISTFT / MODE_ISTFT1 without a stored initial spectrum: angles = S * phase drawn here
     int draw;                 // 1: `spec` holds nothing, the initial phase is drawn in the kernel
     int draw_nzh;             // layout of S: 0 native order, else pair order (pair_s_slot)
@@ -290,6 +293,8 @@ struct Engine {
         run = r;
         block_extra = a.raw_in ? 1 : 0;
         share_next = nullptr;
+        deposit_out = nullptr;
+        deposit_in = nullptr;
         tab.twA = tables;
         tab.twB = tab.twA + G::TW_A;
         tab.twC = tab.twB + G::TW_B;
@@ -357,10 +362,22 @@ struct Engine {
     // that run is a wave of the same workgroup it leaves them in LDS (share_next), and this run
     // takes them from there instead of fetching both halves of both signals again.
     const cf* share_next = nullptr;
+    // Boundary blocks completed on the producer's side.  The R-1 blocks at a run boundary are the
+    // sum of two partial sums: the earlier run's last frames ("tail") and the later run's first
+    // frames ("head").  Normally each goes to a buffer of its own and whoever reads the blocks
+    // adds the two.  Where both runs are waves of one workgroup, the later run leaves its head
+    // sums in LDS as it emits them (deposit_out) and the earlier run, at its end and after a
+    // workgroup barrier, adds its tail sums (deposit_in) and writes the COMPLETE blocks to the
+    // main buffer: nothing goes to the tail buffer, and the next launch reads one half instead of
+    // two.  head + tail in that order, as the reader adds them: the same bits.
+    cf* deposit_out = nullptr;       // this run's first R-1 blocks go here, not to memory
+    const cf* deposit_in = nullptr;  // the next run's deposit: completes this run's last R-1 blocks
     GLV_HD bool from_next(int j) const { return share_next != nullptr && j >= run.t_end; }
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1 + block_extra; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
-        return !a.raw_in && (j >= run.t_end || (run.t_begin > 0 && j < run.t_begin + R - 1));
+        if (a.raw_in) return false;
+        if (j >= run.t_end) return deposit_in == nullptr;                  // else complete in main
+        return run.t_begin > 0 && j < run.t_begin + R - 1 && deposit_out == nullptr;
     }
     GLV_HD void fetch_block(const IterArgs& a, int j, BlockFetch& f) const {
         fetch_block_from(a, a.y_in, a.y_in_tail, j, f);
@@ -929,12 +946,23 @@ struct Engine {
             acc[q].x = fmaf(v[q].x, wn.x, acc[q].x);
             acc[q].y = fmaf(v[q].y, wn.y, acc[q].y);
         }
-        store_block(a, a.y_out, t, acc, 0);
+        if (deposit_out != nullptr && t < run.t_begin + R - 1)
+            deposit_block(t - run.t_begin);
+        else
+            store_block(a, a.y_out, t, acc, 0);
         shift_rows(acc);
 #pragma unroll
         for (int s2 = 0; s2 < A; ++s2)
 #pragma unroll
             for (int r = 8 - HB; r < 8; ++r) acc[r + 8 * s2] = cf{0.f, 0.f};
+    }
+    // block q of this run's head sums (the oldest hop of the running sum) -> LDS, in the layout of
+    // publish_preload
+    GLV_HD void deposit_block(int q) {
+        if constexpr (A == 1) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) deposit_out[(q * HB + i) * (ROW / 2) + lane] = acc[i];
+        }
     }
     // ---- one frame per wave (MODE_ITER1 / MODE_ISTFT1) ----
     // Frame tc writes its windowed output, R whole blocks tc .. tc+R-1, to partial-sum buffer
@@ -1039,6 +1067,16 @@ struct Engine {
 
     // what is left after the last frame belongs to blocks t_end .. t_end+R-2
     GLV_HD void flush_tails(const IterArgs& a) {
+        if constexpr (A == 1) {
+            if (deposit_in != nullptr) {
+                // the next run's head sums + this run's tail sums = the complete blocks
+#pragma unroll
+                for (int row = 0; row < (R - 1) * HB; ++row) acc[row] = deposit_in[row * (ROW / 2) + lane] + acc[row];
+#pragma unroll
+                for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out, run.t_end + q, acc, q * HB);
+                return;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out_tail, run.t_end + q, acc, q * HB);
     }

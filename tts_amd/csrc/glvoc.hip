@@ -70,6 +70,8 @@ struct glv_plan {
     int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
                             // with runs, 0 = never, 1 = always
     bool cur_single = false;    // the run table in place is one run per frame
+    int deposit = 1;            // option: run boundaries inside a workgroup completed by the producer
+    bool cur_deposit = false;   // the tail flags in place (and the call in progress) follow that convention
     float* d_parts = nullptr;   // 2 generations x R partial-sum buffers (one-frame-per-wave modes)
     size_t parts_cap = 0;       // floats
     int64_t parts_utt_stride = 0, parts_stride = 0;  // layout of the call in progress
@@ -371,6 +373,7 @@ IterArgs iter_args(const glv_plan* p, int frames_stride) {
     a.trash = p->d_zeros + p->hop;
     a.tables = p->d_tables;
     a.inv_n = 1.0f / (float)p->n_fft;
+    a.deposit = p->cur_deposit ? 1 : 0;
     return a;
 }
 
@@ -444,7 +447,7 @@ size_t runs_bound(const glv_plan* p, int64_t frames, bool single) {
 // (Re)builds the run table for these lengths and uploads it.  Cached: a call with
 // the lengths of the previous call costs nothing.
 int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st,
-                 bool single = false) {
+                 bool single = false, bool deposit = false) {
     if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
     if (batch < 1 || batch > p->max_batch)
         return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
@@ -456,7 +459,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
                         frames_stride);
     const bool same = (int)p->cur_nframes.size() == batch && p->cur_frames_stride == frames_stride &&
                       p->cur_fpr == p->frames_per_run && p->cur_target == p->run_target &&
-                      p->cur_single == single &&
+                      p->cur_single == single && p->cur_deposit == deposit &&
                       memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
     if (same) return GLV_OK;
     std::vector<RunDesc> runs;
@@ -480,7 +483,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         runs = build_runs_target(n_frames_host, batch, target, p->R);
     }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
-    std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R);
+    std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R, deposit ? kWavesPerBlock : 0);
     glv_plan::Staging* sg = nullptr;
     int rc = acquire_staging(p, &sg);
     if (rc != GLV_OK) return rc;
@@ -509,6 +512,7 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     p->cur_fpr = p->frames_per_run;
     p->cur_target = p->run_target;
     p->cur_single = single;
+    p->cur_deposit = deposit;
     p->n_runs = (int)runs.size();
     return GLV_OK;
 }
@@ -677,6 +681,9 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         p->nnls_fused = value != 0;
     } else if (!strcmp(name, "zero_skip")) {
         p->zero_skip = value != 0;
+    } else if (!strcmp(name, "deposit")) {
+        p->deposit = value != 0;
+        drop_graphs(p);
     } else if (!strcmp(name, "halo_loopback")) {
         p->halo_loopback = value != 0;
     } else if (!strcmp(name, "fuse_draw")) {
@@ -1015,7 +1022,11 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
                                   (p->single_frame < 0 && p->frames_per_run == 0 &&
                                    total_frames <= (int64_t)(8 + 2 * p->A) * p->n_cus &&
                                    padded_blocks <= 4 * (int64_t)p->wave_slots));
-    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single);
+    // Every kernel of a call must agree on who completes a run boundary: the producer does where
+    // all of them can (n_fft 1024, the iteration that keeps no spectrum, no convergence curve).
+    const bool deposit = p->deposit && p->A == 1 && kWavesPerBlock > 1 && !single && three_generations(p) &&
+                         !p->recompute && !(sc_curve_dev != nullptr && n_iter > 0);
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single, deposit);
     if (rc != GLV_OK) return rc;
     if (single) {
         p->parts_utt_stride = (int64_t)(frames_stride + p->R) * p->hop;
@@ -1271,6 +1282,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     HIP_TRY(hipMemcpyAsync(p->d_nframes, sg->ints, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(release_staging(sg, st));
     p->cur_nframes.clear();  // the batch path must rebuild its own tables afterwards
+    p->cur_deposit = false;  // every boundary of a shard is two halves (the flags above say so)
     p->n_runs = (int)runs.size();
     p->shard_t0 = t0;
     p->shard_t1 = t1;

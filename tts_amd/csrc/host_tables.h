@@ -209,17 +209,28 @@ inline int64_t pick_run_target(int64_t total_frames, int cus, int waves_per_bloc
     return best;
 }
 
+// Run i completes its last R-1 blocks itself (Engine::deposit_in): the next run continues its
+// utterance and is a wave of the same workgroup of `waves_per_block` consecutive runs.
+inline bool run_completes_its_tail(const std::vector<RunDesc>& runs, size_t i, int waves_per_block) {
+    return waves_per_block > 1 && (int)(i % (size_t)waves_per_block) + 1 < waves_per_block && i + 1 < runs.size() &&
+           runs[i + 1].utt == runs[i].utt;
+}
+
 // tail_flag[b*blocks_stride + j] = 1 when block j of utterance b is completed by
 // adding the tail buffer (first R-1 blocks after an interior run boundary, and
-// the R-1 blocks past the last frame).
+// the R-1 blocks past the last frame).  deposit_waves > 0: the boundaries that the producer
+// completes inside workgroups of that many runs are not among them.
 inline std::vector<unsigned char> build_tail_flags(const std::vector<RunDesc>& runs, int batch,
-                                                   int blocks_stride, int R) {
+                                                   int blocks_stride, int R, int deposit_waves = 0) {
     std::vector<unsigned char> f((size_t)batch * blocks_stride, 0);
-    for (const RunDesc& r : runs)
+    for (size_t i = 0; i < runs.size(); ++i) {
+        const RunDesc& r = runs[i];
+        if (deposit_waves > 0 && run_completes_its_tail(runs, i, deposit_waves)) continue;
         for (int q = 0; q < R - 1; ++q) {
             const int j = r.t_end + q;
             if (j < blocks_stride) f[(size_t)r.utt * blocks_stride + j] = 1;
         }
+    }
     return f;
 }
 

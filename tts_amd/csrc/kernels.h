@@ -46,6 +46,12 @@ constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 #ifndef GLV_SHARE_BOUNDARY
 #define GLV_SHARE_BOUNDARY 1
 #endif
+// 1: the kernels that can (n_fft 1024: the first inverse transform and the time-domain-momentum
+// iteration without the metric) complete run boundaries inside a workgroup on the producer's side
+// when the call asks for it (IterArgs::deposit); 0: never.
+#ifndef GLV_DEPOSIT
+#define GLV_DEPOSIT 1
+#endif
 
 __device__ __forceinline__ void wave_sync() {
     // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
@@ -81,8 +87,14 @@ template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
     using G = Geo<A>;
-    // the default iteration kernels have registers to spare for the pass twiddles
-    using Eng = Engine<A, HB, (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC>;
+    // Kernels that can complete run boundaries on the producer's side.  They keep every table in
+    // registers (the default iteration kernels have the room anyway), so that after the set-up
+    // the table region of LDS is free to hold the deposits.
+    constexpr bool kCanDeposit = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ISTFT) && !SC &&
+                                 A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
+    using Eng = Engine<A, HB, ((MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC) || kCanDeposit>;
+    static_assert(!kCanDeposit || (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= G::TABLES,
+                  "the deposits of a workgroup must fit the table region");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tables = reinterpret_cast<cf*>(smem);
     GLV_STAMP(0)
@@ -118,7 +130,13 @@ gl_engine_kernel(IterArgs a) {
     constexpr bool kShare = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC && A == 1 &&
                             GLV_SHARE_BOUNDARY;
     const bool live = ri < a.n_runs;
-    if (!live && !kShare) return;
+    const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
+    if (!live) {
+        // a wave without a run only keeps the workgroup's barriers company
+        if (kShare || deposit) __syncthreads();  // after the set-up
+        if (deposit) __syncthreads();            // before the tails are completed
+        return;
+    }
     cf* xb = tables + G::TABLES + wave * G::XBUF;
     cf* shared_blocks = tables + G::TABLES + kWavesPerBlock * G::XBUF;  // [wave][kShareFloats / 2]
 
@@ -129,6 +147,16 @@ gl_engine_kernel(IterArgs a) {
     rd.n_frames = __builtin_amdgcn_readfirstlane(rd.n_frames);
     Eng e;
     e.init(a, tables, lane, rd);
+    if (kCanDeposit && deposit) {
+        // wave w > 0 deposits for wave w - 1 when its run continues that wave's utterance
+        cf* area = tables;  // [wave - 1][kShareFloats / 2], over the tables once every wave has read them
+        if (wave > 0 && __builtin_amdgcn_readfirstlane(a.runs[ri - 1].utt) == rd.utt)
+            e.deposit_out = area + (wave - 1) * (Eng::kShareFloats / 2);
+        if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs &&
+            __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt) == rd.utt)
+            e.deposit_in = area + wave * (Eng::kShareFloats / 2);
+    }
+    if (!kShare && deposit) __syncthreads();  // every wave has taken its tables out of LDS
     constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
     constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1;
     if (kSingle) {
@@ -182,7 +210,6 @@ gl_engine_kernel(IterArgs a) {
             e.publish_preload(mine);
         }
         __syncthreads();
-        if (!live) return;
         // the next run, if it continues this utterance inside this workgroup
         if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
             const int next_utt = __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt);
@@ -303,6 +330,7 @@ gl_engine_kernel(IterArgs a) {
         e.ph6(a, t, xb);
         wave_sync();
     }
+    if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
     GLV_STAMP(3)
     if (SC) {
