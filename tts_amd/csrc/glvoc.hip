@@ -1267,8 +1267,13 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     auto mark = [&](int j) {
         if (j - t0 >= 0 && j - t0 < p->blocks) flags[j - t0] = 1;
     };
-    for (const RunDesc& r : runs)
-        for (int q = 0; q < p->R - 1; ++q) mark(r.t_end + q);
+    // (inside the shard the producer completes the run boundaries it can, as in the batch path;
+    // the shard's own edges always travel as two halves)
+    const bool deposit = p->deposit && p->A == 1 && kWavesPerBlock > 1 && p->linear && !p->recompute && !p->traffic_only;
+    for (size_t i = 0; i < runs.size(); ++i) {
+        if (deposit && run_completes_its_tail(runs, i, kWavesPerBlock)) continue;
+        for (int q = 0; q < p->R - 1; ++q) mark(runs[i].t_end + q);
+    }
     if (t0 > 0)
         for (int q = 0; q < p->R - 1; ++q) mark(t0 + q);  // tails of the previous shard's last run
     glv_plan::Staging* sg = nullptr;
@@ -1282,7 +1287,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     HIP_TRY(hipMemcpyAsync(p->d_nframes, sg->ints, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(release_staging(sg, st));
     p->cur_nframes.clear();  // the batch path must rebuild its own tables afterwards
-    p->cur_deposit = false;  // every boundary of a shard is two halves (the flags above say so)
+    p->cur_deposit = deposit;
     p->n_runs = (int)runs.size();
     p->shard_t0 = t0;
     p->shard_t1 = t1;
