@@ -46,6 +46,8 @@ def main():
     got = synthesize_sharded(mels, MEAN, STD, compute_fn=compute, **kw)
     # (b) phases drawn on the device from (seed, utterance identity): against one call
     drawn = synthesize_sharded(mels, MEAN, STD, seed=17, **kw)
+    # the same with the gather cut into pieces that travel under the synthesis of the next piece
+    pieces = synthesize_sharded(mels, MEAN, STD, seed=17, gather_chunks=3, **kw)
     ok = True
     if rank == 0:
         worst = 0.0
@@ -57,7 +59,8 @@ def main():
         one, n = griffin_lim_batch(mels, MEAN, STD, seed=17, utt_ids=list(range(len(lens))),
                                    frames_per_run=SHARDED_FRAMES_PER_RUN, **kw)[:2]
         one = one.cpu().numpy()
-        identical = all(np.array_equal(drawn[i], one[i, :n[i]]) for i in range(len(lens)))
+        identical = all(np.array_equal(drawn[i], one[i, :n[i]]) and np.array_equal(pieces[i], one[i, :n[i]])
+                        for i in range(len(lens)))
         print(f"batch-sharded over {dist.get_world_size()} processes ({backend}): worst rel L2 vs oracle "
               f"{worst:.3e}; bit-identical to one call: {identical}")
         ok &= worst < 1e-4 and identical

@@ -52,6 +52,14 @@ def _worker(rank, world, port, tmpdir):
     from tts_amd import distributed as D
     mels = _make_mels()
     res = D.synthesize_sharded(mels, MEAN, STD, compute_fn=_oracle_batch, hop_length=256, n_fft=1024)
+    # the gather in pieces (each started as soon as its piece is synthesised) brings the same arrays
+    for chunks in (2, 3, 9):
+        again = D.synthesize_sharded(mels, MEAN, STD, compute_fn=_oracle_batch, hop_length=256, n_fft=1024,
+                                     gather_chunks=chunks)
+        if rank == 0:
+            assert len(again) == len(res) and all(np.array_equal(a, b) for a, b in zip(again, res)), chunks
+        else:
+            assert sorted(again) == sorted(res)
     if rank == 0:
         np.savez(os.path.join(tmpdir, "gathered.npz"), *res)
     else:

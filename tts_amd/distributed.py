@@ -47,12 +47,17 @@ SHARDED_FRAMES_PER_RUN = 32
 
 
 def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=None, seed=0,
-                       frames_per_run=SHARDED_FRAMES_PER_RUN, return_tensors=False, **kw):
+                       frames_per_run=SHARDED_FRAMES_PER_RUN, return_tensors=False, gather_chunks=1, **kw):
     """Batch-sharded synthesis.  `mels` is the full list of (T_i, n_mels) arrays, present on
     every rank.  Each rank synthesises `shard_by_length(...)[rank]` with `compute_fn`
     (default: `griffin_lim_batch` on its GPU) - no communication - and, unless `gather_dst`
     is None, ONE gather brings the padded (rows, samples) blocks to rank `gather_dst`: device
     tensors under RCCL, host tensors under a transport that only moves host memory (gloo).
+
+    `gather_chunks` > 1 cuts every rank's shard into that many pieces and starts the gather of a
+    piece as soon as it is synthesised, so that the transfer of piece i runs (on the
+    communicator's stream) under the synthesis of piece i + 1 and only the last piece's transfer
+    is exposed; the result is the same bits.
 
     Every utterance keeps its identity (its index in `mels`) for the device-drawn initial phase
     and is cut into runs by a rule that depends on its own length only, so the waveforms are
@@ -72,39 +77,59 @@ def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=
     mine = shards[rank]
     hop = kw.get("hop_length", 256)
     n_out = [hop * (t - 1) for t in lengths]
-    audio = None
-    if mine:
-        audio = compute_fn([mels[i] for i in mine], mean, std, utt_ids=list(mine), seed=seed,
-                           frames_per_run=frames_per_run, **kw)[0]
-        audio = audio.detach() if isinstance(audio, torch.Tensor) else torch.from_numpy(np.asarray(audio))
+    max_len = max(n_out)
+    gathering = distributed and gather_dst is not None
+    # piece c of a rank = a contiguous slice of its (index-ordered) shard; every rank derives all
+    # pieces of all ranks from the lengths it knows, hence the common block shapes: no size exchange
+    n_chunks = max(1, int(gather_chunks)) if gathering else 1
+
+    def piece(idxs, c):
+        per = -(-len(idxs) // n_chunks)
+        return idxs[c * per:(c + 1) * per]
+
+    on_device = distributed and dist.get_backend(group) == "nccl"
 
     def finish(row):
         return row if return_tensors else row.cpu().numpy()
 
-    local = {i: audio[r, : n_out[i]] for r, i in enumerate(mine)}
+    local, pending = {}, []
+    for c in range(n_chunks):
+        part = piece(mine, c)
+        audio = None
+        if part:
+            audio = compute_fn([mels[i] for i in part], mean, std, utt_ids=list(part), seed=seed,
+                               frames_per_run=frames_per_run, **kw)[0]
+            audio = audio.detach() if isinstance(audio, torch.Tensor) else torch.from_numpy(np.asarray(audio))
+            for r, i in enumerate(part):
+                local[i] = audio[r, : n_out[i]]
+        if not gathering:
+            continue
+        rows = max(len(piece(sh, c)) for sh in shards)
+        if rows == 0:
+            continue
+        where = audio.device if (audio is not None and on_device) else (
+            torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
+        block = torch.zeros((rows, max_len), dtype=torch.float32, device=where)
+        if audio is not None:
+            block[: audio.shape[0], : audio.shape[1]] = audio[:, :max_len].to(where)
+        parts = [torch.empty_like(block) for _ in range(world)] if rank == gather_dst else None
+        # asynchronous: the transfer waits for this piece on the device and runs beside the next one
+        work = dist.gather(block, parts, dst=gather_dst, group=group, async_op=True)
+        pending.append((c, block, parts, work))
     if not distributed:
         return [finish(local[i]) for i in range(len(mels))]
     if gather_dst is None:
         return {i: finish(v) for i, v in local.items()}
-    # every rank knows all lengths, hence the common block shape: no size exchange
-    max_rows = max(len(s) for s in shards)
-    max_len = max(n_out)
-    on_device = dist.get_backend(group) == "nccl"
-    where = audio.device if (audio is not None and on_device) else (
-        torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu"))
-    block = torch.zeros((max_rows, max_len), dtype=torch.float32, device=where)
-    if audio is not None:
-        block[: audio.shape[0], : audio.shape[1]] = audio[:, :max_len].to(where)
-    if rank == gather_dst:
-        parts = [torch.empty_like(block) for _ in range(world)]
-        dist.gather(block, parts, dst=gather_dst, group=group)
-        out = [None] * len(mels)
+    for _, _, _, work in pending:
+        work.wait()
+    if rank != gather_dst:
+        return {i: finish(v) for i, v in local.items()}
+    out = [None] * len(mels)
+    for c, _, parts, _ in pending:
         for r, idxs in enumerate(shards):
-            for k, i in enumerate(idxs):
+            for k, i in enumerate(piece(idxs, c)):
                 out[i] = finish(parts[r][k, : n_out[i]])
-        return out
-    dist.gather(block, None, dst=gather_dst, group=group)
-    return {i: finish(v) for i, v in local.items()}
+    return out
 
 
 def split_frames(n_frames, world_size, min_frames=1):
