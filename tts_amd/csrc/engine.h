@@ -215,6 +215,9 @@ GLV_HD int native_s_index(int reg, int lane);
 template <int A>
 GLV_HD int pair_s_slot(int nzh, int reg, int lane);
 GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx);
+GLV_HD uint32_t counter_high_part(uint64_t seed, uint32_t idx_high);
+GLV_HD float counter_uniform_low(uint32_t high_part, uint32_t idx_low);
+GLV_HD cf phasor_of(float u);
 
 // TWR: the twiddles of the first and second FFT pass stay in registers for the whole run as
 // well (n_fft 1024 only; 26 more registers, 12 fewer 16-byte LDS reads per frame) - for the
@@ -906,16 +909,24 @@ struct Engine {
         const uint64_t key = a.draw_seed ^ (id * 0x9E3779B97F4A7C15ull);
         const uint64_t first = (uint64_t)((t + a.draw_origin) * (P + 1));
         const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+        // the generator's seed-and-high-word part is the same for the whole frame unless the frame
+        // straddles a multiple of 2^32 elements: computed once then (the same values either way)
+        const bool one_high = (uint32_t)(first >> 32) == (uint32_t)((first + (uint64_t)P) >> 32);
+        const uint32_t high_part = counter_high_part(key, (uint32_t)(first >> 32));
+        auto phasor_at = [&](int k) -> cf {
+            if (one_high) return phasor_of(counter_uniform_low(high_part, (uint32_t)first + (uint32_t)k));
+            return counter_phasor(key, first + (uint64_t)k);
+        };
 #pragma unroll
         for (int reg = 0; reg < E; ++reg) {
             const int slot = a.draw_nzh ? pair_s_slot<A>(a.draw_nzh, reg, lane) : native_s_index(reg, lane);
             const float s = slot >= 0 ? sf[slot] : 0.0f;
-            const cf ph = counter_phasor(key, first + (uint64_t)G::bin(reg, lane));
+            const cf ph = phasor_at(G::bin(reg, lane));
             v[reg] = cf{ph.x * s * a.inv_n, ph.y * s * a.inv_n};
         }
         if (lane == 0) {
             // DC and Nyquist are real and share native bin 0 (the inverse ignores their Im)
-            const cf pn = counter_phasor(key, first + (uint64_t)P);
+            const cf pn = phasor_at(P);
             v[0].y = pn.x * sf[P] * a.inv_n;
         }
     }
@@ -1141,8 +1152,15 @@ GLV_HD float counter_uniform(uint64_t seed, uint64_t idx) {
     const uint32_t x = mix32((uint32_t)idx ^ mix32((uint32_t)seed + hi));
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx) {
-    const float u = counter_uniform(seed, idx);
+// The part of counter_uniform that depends on the seed and on the high word of the index only,
+// and the rest: counter_uniform(seed, idx) == counter_uniform_low(counter_high_part(seed, idx >> 32), idx).
+GLV_HD uint32_t counter_high_part(uint64_t seed, uint32_t idx_high) {
+    return mix32((uint32_t)seed + mix32(idx_high ^ (uint32_t)(seed >> 32) ^ 0x9E3779B9u));
+}
+GLV_HD float counter_uniform_low(uint32_t high_part, uint32_t idx_low) {
+    return (float)(mix32(idx_low ^ high_part) >> 8) * (1.0f / 16777216.0f);
+}
+GLV_HD cf phasor_of(float u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return cf{__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u)};
 #else
@@ -1150,5 +1168,6 @@ GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx) {
     return cf{cosf(ph), sinf(ph)};
 #endif
 }
+GLV_HD cf counter_phasor(uint64_t seed, uint64_t idx) { return phasor_of(counter_uniform(seed, idx)); }
 
 }  // namespace glv
