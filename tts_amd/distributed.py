@@ -192,7 +192,9 @@ def _halo_chain(group, rank, world, device):
     """The library-side communicator of `group` on this device: made on first use (collective:
     rank 0's id travels through the group), then kept for the life of the process."""
     from .vocoder import HaloChain
-    key = (id(group) if group is not None else None, world, rank, str(device))
+    # (keyed by the group's members, not the group object, whose identity can be reused)
+    members = tuple(dist.get_process_group_ranks(group)) if group is not None else None
+    key = (members, world, rank, str(device))
     chain = _HALO_CHAINS.get(key)
     if chain is None:
         box = [HaloChain.unique_id() if rank == 0 else None]
