@@ -1021,10 +1021,10 @@ def test_library_halo_exchange_over_rccl_to_itself(voc, n_fft, hop):
     chain.close()
 
 
-@pytest.mark.parametrize("n_fft,hop,lens,fpr", [(1024, 256, [64, 40, 21, 2, 9], 0), (1024, 256, [150, 33], 5),
-                                                (1024, 128, [50, 12, 64], 9), (1024, 512, [40, 17], 0),
-                                                (2048, 256, [48, 30], 0)])
-def test_run_boundaries_completed_by_the_producer(voc, n_fft, hop, lens, fpr):
+@pytest.mark.parametrize("n_fft,hop,win,lens,fpr", [(1024, 256, 1024, [64, 40, 21, 2, 9], 0), (1024, 256, 1024, [150, 33], 5),
+                                                    (1024, 128, 1024, [50, 12, 64], 9), (1024, 512, 1024, [40, 17], 0),
+                                                    (1024, 256, 800, [70, 31, 6], 3), (2048, 256, 2048, [48, 30], 0)])
+def test_run_boundaries_completed_by_the_producer(voc, n_fft, hop, win, lens, fpr):
     """Option "deposit": where consecutive runs of an utterance are waves of one workgroup the later
     run hands its head sums over through LDS and the earlier one writes the boundary blocks
     complete, instead of both writing halves that every reader adds.  The same additions in the
@@ -1042,7 +1042,7 @@ def test_run_boundaries_completed_by_the_producer(voc, n_fft, hop, lens, fpr):
         s[i, :t] = rng.standard_normal((t, f)) ** 2
         ang = 2 * np.pi * rng.random((t, f))
         p0[i, :t, :, 0], p0[i, :t, :, 1] = np.cos(ang), np.sin(ang)
-    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t_max, b)
+    plan = voc.GriffinLimPlan(n_fft, hop, win, 80, t_max, b)
     plan.set_mel_basis(22050, 0.0, 8000)
     plan.set_option("single_frame", 0)
     plan.set_option("frames_per_run", fpr)
