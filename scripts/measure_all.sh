@@ -45,4 +45,6 @@ BENCH_ARGS="--n-fft 2048 --frames 865" scripts/pmc_gpu.sh "${TAG}_n2048" "$G1" "
 # the NNLS solver: matrix-core counters of its one kernel
 GM="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE"
 KERNEL_FILTER=nnls_fused_kernel BENCH_ARGS="--inversion nnls" scripts/pmc_gpu.sh "${TAG}_nnls" "$GM" > "$OUT/pmc_nnls.log" 2>&1 || { echo "pmc nnls failed"; tail -5 "$OUT/pmc_nnls.log"; exit 1; }
+# the pseudo-inverse product (mel_native_kernel): the same matrix-core counters
+KERNEL_FILTER=mel_native_kernel scripts/pmc_gpu.sh "${TAG}_melnative" "$GM" > "$OUT/pmc_melnative.log" 2>&1 || { echo "pmc mel_native failed"; tail -5 "$OUT/pmc_melnative.log"; exit 1; }
 echo done
