@@ -176,7 +176,12 @@ int glv_peak_normalize(glv_plan* plan, float* y_dev, const int* n_samples_host, 
  *   - the per-row maxima live in a fixed device array inside the library (128 KiB per GPU, held
  *     until the process ends), so batch <= 32768; larger batches are refused with
  *     GLV_ERR_INVALID;
- *   - it calls no hipMalloc / hipFree and takes no lock on the device.
+ *   - it calls no hipMalloc / hipFree and does not synchronise the device;
+ *   - the device address of that array is looked up once per GPU (hipGetSymbolAddress, which may
+ *     load the code object and is not a stream operation): by glv_plan_create for the plan's
+ *     device, else by the first call on the device - make that first call OUTSIDE stream capture
+ *     in a process that never created a plan there.  Later calls read the stored address without
+ *     taking a lock.
  * Every call on a GPU uses that GPU's one array: calls that overlap in time on one GPU (two
  * streams, two threads) race on it - serialise them.
  */
@@ -341,6 +346,19 @@ int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
  */
 int glv_plan_set_option(glv_plan* plan, const char* name, int value);
 int glv_plan_last_loop_ms(glv_plan* plan, float* ms_out);
+
+/*
+ * Writes the initial phase the library draws when a call passes phase0_dev == NULL: the unit
+ * phasors of (seed, utterance identity, frame, bin) for `batch` utterances, as (batch,
+ * frames_stride, F) interleaved pairs - exactly what glv_griffinlim / glv_mel_to_audio use for the
+ * same seed and the identities in place (glv_plan_set_utterance_ids).  frame_origin is the global
+ * index of row 0's first frame (0, or the shard's first frame for glv_shard_begin).  A checking aid:
+ * it lets another implementation of librosa.griffinlim (reference vocoder/mel_audio.py:126) run on
+ * the very phase a device-drawn call used.  No counterpart in the reference, whose phase is an
+ * unseeded default_rng.
+ */
+int glv_plan_drawn_phase(glv_plan* plan, uint64_t seed, int batch, int frames_stride, int64_t frame_origin,
+                         float* phase_dev, void* stream);
 
 const char* glv_last_error(void);
 

@@ -18,6 +18,7 @@ def main():
     from tts_amd.vocoder import GriffinLimPlan
     n_fft, hop, frames, n_iter = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 6
     backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
+    transport = sys.argv[5] if len(sys.argv) > 5 else None
     torch.cuda.set_device(0)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
@@ -27,7 +28,7 @@ def main():
     gather_device = "cuda:0" if backend == "nccl" else "cpu"
     mel = synthetic_mel(77, frames)
     y, n_begin = griffin_lim_time_sharded(mel, MEAN, STD, n_fft=n_fft, hop_length=hop, n_iter=n_iter, seed=5,
-                                          device=torch.device("cuda:0"))
+                                          device=torch.device("cuda:0"), transport=transport)
     piece = y.to(gather_device)
     meta = torch.tensor([n_begin, piece.numel()], dtype=torch.int64, device=gather_device)
     metas = [torch.zeros(2, dtype=torch.int64, device=gather_device) for _ in range(world)]

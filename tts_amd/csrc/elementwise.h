@@ -18,6 +18,9 @@ struct LayoutArgs {
                               // null: its position in the batch
     int s_pair_nzh;           // 0: magnitudes in native order; else pair order (pair_s_slot) with
                               // that many possibly non-zero mirrors per lane
+    int block_origin;         // time shard: the overlap-add buffers and tail flags start at this block
+                              // of the utterance, and `out` at sample out_origin of the waveform
+    int64_t out_origin;
 };
 
 // Device-drawn initial phase of (utterance b, frame t, bin k): the stream is keyed by the
@@ -101,13 +104,13 @@ GLV_HD float finalize_sample(const LayoutArgs& L, const float* y_main, const flo
     if (n < len) {
         const int64_t p = n + L.n_fft / 2;
         const int j = (int)(p / L.hop), s = (int)(p % L.hop);
-        const int64_t at = (int64_t)b * L.y_utt_stride + p;
+        const int64_t at = (int64_t)b * L.y_utt_stride + p - (int64_t)L.block_origin * L.hop;
         if (j < T) val = y_main[at];
-        if (tail_flag[(int64_t)b * blocks_stride + j]) val += y_tail[at];
+        if (tail_flag[(int64_t)b * blocks_stride + j - L.block_origin]) val += y_tail[at];
         const float iw = iwss_row(iwss, iwss_head, iwss_tail, iwss_small, L.hop, L.R, T, j)[s];
         val *= iw;
     }
-    out[(int64_t)b * out_stride + n] = val;
+    out[(int64_t)b * out_stride + n - L.out_origin] = val;
     return fabsf(val);
 }
 

@@ -133,6 +133,9 @@ struct IterArgs {
     uint64_t draw_seed;
     const int64_t* draw_ids;  // [batch] utterance identities of the phase stream, or null: the row
     int64_t draw_origin;      // global index of local frame 0
+    // Time shard: runs, frames and blocks are numbered over the whole utterance, while spec, S and
+    // the overlap-add buffers hold only the shard - index 0 there is frame / block t_origin.
+    int t_origin;
 };
 
 // Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
@@ -388,7 +391,7 @@ struct Engine {
     GLV_HD void fetch_block_from(const IterArgs& a, const float* y_main, const float* y_tail, int j,
                                  BlockFetch& f) const {
         const bool valid = block_valid(j) && !from_next(j);
-        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)(j - a.t_origin) * H;
         const float* pm = (valid && (a.raw_in || j < run.n_frames)) ? y_main + base : a.zeros;
         const float* pt = (valid && block_has_tail(a, j)) ? y_tail + base : a.zeros;
         const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
@@ -449,7 +452,7 @@ struct Engine {
         const bool valid = block_valid(j) && !from_next(j);
         const bool has_main = valid && (a.raw_in || j < run.n_frames);
         const bool has_tail = valid && block_has_tail(a, j);
-        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H;
+        const int64_t base = (int64_t)run.utt * a.y_utt_stride + (int64_t)(j - a.t_origin) * H;
         const float* pm = has_main ? a.y_in + base : a.zeros;
         const float* pmp = has_main ? a.y_prev + base : a.zeros;
         const float* pt = has_tail ? a.y_in_tail + base : a.zeros;
@@ -472,7 +475,7 @@ struct Engine {
     }
     GLV_HD void prefetch_s(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
-        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)(tt - a.t_origin) * (P + 4);
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
             const f4 sq = ld_stream(reinterpret_cast<const f4*>(sf) + q * 64 + lane);
@@ -486,7 +489,7 @@ struct Engine {
 
     // rows row0 .. row0+HB-1 of a time-side register array -> block j
     GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf (&src)[E], int row0) const {
-        float* p = block_valid(j) ? dst + (int64_t)run.utt * a.y_utt_stride + (int64_t)j * H : a.trash;
+        float* p = block_valid(j) ? dst + (int64_t)run.utt * a.y_utt_stride + (int64_t)(j - a.t_origin) * H : a.trash;
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
             if (A == 1) {
@@ -635,7 +638,7 @@ struct Engine {
     GLV_HD void ph2_write(cf* w) { F::mirror_store(v, w, lane); }
 
     GLV_HD cf* spec_frame(const IterArgs& a, int t) const {
-        return a.spec + (int64_t)run.utt * a.spec_utt_stride + (int64_t)t * P;
+        return a.spec + (int64_t)run.utt * a.spec_utt_stride + (int64_t)(t - a.t_origin) * P;
     }
 
     // ---- phase 3 (STFT only): finish the split and store the frame ----
@@ -721,7 +724,7 @@ struct Engine {
     template <int NZH>
     GLV_HD void prefetch_s_pair(const IterArgs& a, int t) {
         const int tt = t < run.t_end ? t : run.t_end - 1;
-        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)tt * (P + 4);
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)(tt - a.t_origin) * (P + 4);
 #pragma unroll
         for (int g = 0; g < NP / 4; ++g) {
             const f4 sq = ld_stream(reinterpret_cast<const f4*>(sf) + g * 64 + lane);
@@ -908,7 +911,7 @@ struct Engine {
         const uint64_t id = a.draw_ids ? (uint64_t)a.draw_ids[run.utt] : (uint64_t)run.utt;
         const uint64_t key = a.draw_seed ^ (id * 0x9E3779B97F4A7C15ull);
         const uint64_t first = (uint64_t)((t + a.draw_origin) * (P + 1));
-        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)t * (P + 4);
+        const float* sf = a.S + (int64_t)run.utt * a.s_utt_stride + (int64_t)(t - a.t_origin) * (P + 4);
         // the generator's seed-and-high-word part is the same for the whole frame unless the frame
         // straddles a multiple of 2^32 elements: computed once then (the same values either way)
         const bool one_high = (uint32_t)(first >> 32) == (uint32_t)((first + (uint64_t)P) >> 32);

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +44,8 @@ extern "C" const char* glv_last_error(void) { return g_err; }
 extern "C" int glv_version(void) { return 100; }
 
 #include "kernels.h"
+
+static int noalloc_warm_up_current_device();  // defined with glv_peak_normalize_noalloc
 
 
 // ---------------------------------------------------------------------------
@@ -114,6 +117,7 @@ struct glv_plan {
     unsigned* d_peak = nullptr;
     int64_t* d_utt_ids = nullptr;  // identities for the device-drawn phase (glv_plan_set_utterance_ids)
     bool have_ids = false;
+    int n_ids = 0;  // identities uploaded by the last glv_plan_set_utterance_ids
     float* d_sc_partial = nullptr;
     size_t sc_partial_cap = 0;
     int64_t ws_bytes = 0;
@@ -348,7 +352,7 @@ ElemArgs elem_args(const glv_plan* p, int batch, int frames_stride) {
     ElemArgs ea;
     ea.L = LayoutArgs{p->n_fft, p->hop, p->F, p->P, p->R, frames_stride,
                       (int64_t)p->blocks * p->hop, p->d_nframes, 0, 0,
-                      p->have_ids ? p->d_utt_ids : nullptr};
+                      p->have_ids ? p->d_utt_ids : nullptr, 0, 0, 0};
     ea.batch = batch;
     return ea;
 }
@@ -637,6 +641,10 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     PLAN_TRY(hipEventCreate(&p->ev1));
     PLAN_TRY(hipDeviceSynchronize());
 #undef PLAN_TRY
+    if (noalloc_warm_up_current_device() != GLV_OK) {
+        plan_free(p);
+        return GLV_ERR_HIP;
+    }
     {
         // what the automatic choices can ask for: one frame per wave up to 4 x wave_slots padded
         // blocks, and a 64-iteration convergence curve over the automatic run table
@@ -714,6 +722,7 @@ extern "C" int glv_plan_set_utterance_ids(glv_plan* p, const int64_t* ids_host, 
     if (!p) return fail(GLV_ERR_INVALID, "null plan");
     if (!ids_host) {
         p->have_ids = false;
+        p->n_ids = 0;
         return GLV_OK;
     }
     if (batch < 1 || batch > p->max_batch)
@@ -727,6 +736,25 @@ extern "C" int glv_plan_set_utterance_ids(glv_plan* p, const int64_t* ids_host, 
     HIP_TRY(hipMemcpyAsync(p->d_utt_ids, sg->ids, sizeof(int64_t) * batch, hipMemcpyHostToDevice, st));
     HIP_TRY(release_staging(sg, st));
     p->have_ids = true;
+    p->n_ids = batch;
+    return GLV_OK;
+}
+
+extern "C" int glv_plan_drawn_phase(glv_plan* p, uint64_t seed, int batch, int frames_stride, int64_t frame_origin,
+                                    float* phase_dev, void* stream) {
+    if (!p || !phase_dev) return fail(GLV_ERR_INVALID, "null argument");
+    if (batch < 1 || batch > p->max_batch || frames_stride < 1 || frame_origin < 0)
+        return fail(GLV_ERR_INVALID, "batch %d outside [1, %d], or frames_stride / frame_origin not positive", batch,
+                    p->max_batch);
+    if (p->have_ids && batch > p->n_ids)
+        return fail(GLV_ERR_INVALID, "batch %d but only %d utterance identities are set", batch, p->n_ids);
+    DeviceGuard guard(p->device);
+    ElemArgs ea = elem_args(p, batch, frames_stride);
+    ea.L.frame_origin = frame_origin;
+    const int64_t total = (int64_t)batch * frames_stride * p->F;
+    hipLaunchKernelGGL(drawn_phase_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, ea, seed,
+                       reinterpret_cast<cf*>(phase_dev));
+    HIP_TRY(hipGetLastError());
     return GLV_OK;
 }
 
@@ -1009,6 +1037,9 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
     if (batch < 1 || batch > p->max_batch)
         return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
+    if (phase0_dev == nullptr && p->have_ids && batch > p->n_ids)
+        return fail(GLV_ERR_INVALID, "batch %d but glv_plan_set_utterance_ids gave only %d identities", batch,
+                    p->n_ids);
     // A batch of few frames cannot fill the device with runs of several frames: every frame then
     // gets a wave of its own (partial-sum buffers instead of a running sum).  Measured against the
     // best run table: faster up to about 10 frames per CU at n_fft 1024 and 12 at n_fft 2048 (6.2
@@ -1215,22 +1246,12 @@ extern "C" int glv_mel_to_audio(glv_plan* p, const float* mel_db_dev, float mean
 // ---------------------------------------------------------------------------
 namespace {
 
-// Engine arguments in GLOBAL frame / block coordinates: base pointers are moved back by the
-// shard's origin so that frame t and block j of the whole utterance address local storage.
+// Engine arguments in GLOBAL frame / block coordinates: runs, frames and blocks are numbered over
+// the whole utterance, and the engine subtracts the shard's origin where it addresses storage.
 IterArgs shard_iter_args(const glv_plan* p) {
     IterArgs a = iter_args(p, p->max_frames);
-    const int64_t t0 = p->shard_t0;
-    a.spec = p->d_spec - t0 * p->P;
-    a.S = p->d_S - t0 * (p->P + 4);
+    a.t_origin = p->shard_t0;
     return a;
-}
-
-void shard_set_io(const glv_plan* p, IterArgs& a, int in, int out) {
-    const int64_t off = (int64_t)p->shard_t0 * p->hop;
-    a.y_in = p->d_ym[in] - off;
-    a.y_in_tail = p->d_yt[in] - off;
-    a.y_out = p->d_ym[out] - off;
-    a.y_out_tail = p->d_yt[out] - off;
 }
 
 int shard_check(const glv_plan* p) {
@@ -1310,7 +1331,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
                    p->d_spec, st);
     HIP_TRY(hipGetLastError());
     IterArgs a = shard_iter_args(p);
-    shard_set_io(p, a, 1, 0);
+    set_io(p, a, 1, 0);
     HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
     return GLV_OK;
 }
@@ -1327,14 +1348,13 @@ extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
         // momentum in the time domain: the halo swap has completed both older generations, so
         // the previous signal is as local as the current one
         const int cur = p->shard_cur, out = (cur + 1) % 3, prev = p->shard_k == 0 ? cur : (cur + 2) % 3;
-        const int64_t off = (int64_t)p->shard_t0 * p->hop;
-        shard_set_io(p, a, cur, out);
-        a.y_prev = p->d_ym[prev] - off;
-        a.y_prev_tail = p->d_yt[prev] - off;
+        set_io(p, a, cur, out);
+        a.y_prev = p->d_ym[prev];
+        a.y_prev_tail = p->d_yt[prev];
         HIP_TRY(p->launch_engine(MODE_ITER_LIN, false, a, engine_grid(p), (hipStream_t)stream));
         p->shard_cur = out;
     } else {
-        shard_set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
+        set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
         HIP_TRY(p->launch_engine(MODE_ITER, false, a, engine_grid(p), (hipStream_t)stream));
         p->shard_cur ^= 1;
     }
@@ -1418,11 +1438,12 @@ extern "C" int glv_shard_end(glv_plan* p, float* y_dev, void* stream) {
     glv_shard_output_range(p, &n_begin, &n_count);
     if (n_count > 0) {
         ElemArgs ea = elem_args(p, 1, p->max_frames);
-        const int64_t off = (int64_t)p->shard_t0 * p->hop;
+        ea.L.block_origin = p->shard_t0;
+        ea.L.out_origin = n_begin;
         const int cur = p->shard_cur;
         hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(n_count, 256), 1), dim3(256), 0, (hipStream_t)stream,
-                           ea, p->d_ym[cur] - off, p->d_yt[cur] - off, p->d_flags - p->shard_t0, p->blocks,
-                           p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev - n_begin,
+                           ea, p->d_ym[cur], p->d_yt[cur], p->d_flags, p->blocks,
+                           p->d_w2, p->d_iwss, p->d_iwss_head, p->d_iwss_tail, p->d_iwss_small, y_dev,
                            n_count, n_begin, (unsigned*)nullptr);
         HIP_TRY(hipGetLastError());
     }
@@ -1457,16 +1478,19 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
+    std::string why;  // why it is not usable (kept: dlerror() clears itself once read)
 };
 constexpr int kRcclFloat32 = 7;  // ncclFloat32
 
-RcclApi* rccl_api() {
+RcclApi& rccl_state() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.lib) break;
+            const char* err = dlerror();
+            api.why = err ? err : "librccl.so.1 cannot be loaded";
         }
         if (!api.lib) return;
         auto sym = [&](const char* n) { return dlsym(api.lib, n); };
@@ -1480,9 +1504,16 @@ RcclApi* rccl_api() {
         api.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv &&
                  api.GroupStart && api.GroupEnd && api.GetErrorString;
+        if (!api.ok) api.why = "librccl.so.1 lacks one of the ncclSend / ncclRecv / ncclGroup* entry points";
     });
+    return api;
+}
+RcclApi* rccl_api() {
+    RcclApi& api = rccl_state();
     return api.ok ? &api : nullptr;
 }
+// the reason rccl_api() returned null
+const char* rccl_why() { return rccl_state().why.c_str(); }
 
 #define RCCL_TRY(api, expr)                                                                    \
     do {                                                                                       \
@@ -1495,7 +1526,7 @@ RcclApi* rccl_api() {
 extern "C" int glv_halo_unique_id(void* id_out) {
     if (!id_out) return fail(GLV_ERR_INVALID, "null argument");
     RcclApi* api = rccl_api();
-    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "RCCL is not usable: %s", rccl_why());
     RcclId id;
     RCCL_TRY(api, api->GetUniqueId(&id));
     memcpy(id_out, id.internal, GLV_HALO_ID_BYTES);
@@ -1508,7 +1539,7 @@ extern "C" int glv_halo_create(glv_halo** out, const void* id, int rank, int wor
     if (world < 1 || rank < 0 || rank >= world)
         return fail(GLV_ERR_INVALID, "rank %d outside [0, %d)", rank, world);
     RcclApi* api = rccl_api();
-    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "RCCL is not usable: %s", rccl_why());
     DeviceGuard guard(device);
     if (!guard.ok) return fail(GLV_ERR_HIP, "hipSetDevice(%d) failed", device);
     RcclId uid;
@@ -1543,7 +1574,7 @@ extern "C" int glv_shard_exchange(glv_plan* p, void* stream) {
     if (!p->halo) return fail(GLV_ERR_STATE, "glv_halo_attach has not been called");
     const glv_halo* h = p->halo;
     RcclApi* api = rccl_api();
-    if (!api) return fail(GLV_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded");
+    if (!api) return fail(GLV_ERR_UNSUPPORTED, "RCCL is not usable: %s", rccl_why());
     float *send_prev, *send_next, *recv_prev, *recv_next;
     rc = glv_shard_halo_views(p, &send_prev, &send_next, &recv_prev, &recv_next);
     if (rc != GLV_OK) return rc;
@@ -1661,26 +1692,39 @@ static __device__ __align__(256) unsigned scratch[GLV_NOALLOC_MAX_BATCH];
 
 namespace {
 constexpr int kMaxDevices = 64;
-unsigned* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on every GPU seen so far
+// device address of `scratch` on every GPU seen so far (written once per device)
+std::atomic<unsigned*> g_scratch_ptr[kMaxDevices];
 std::mutex g_scratch_mutex;
 
 // The array's name is a host-side handle, not a device address: the address each GPU holds its
-// copy at is looked up once per device, with that device current.
+// copy at is looked up once per device, with that device current.  The look-up (which may load
+// the code object) happens in glv_plan_create or in the first glv_peak_normalize_noalloc on the
+// device; later calls only read the stored address and take no lock.
 int scratch_for_current_device(unsigned** out) {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(GLV_ERR_UNSUPPORTED, "device index %d not supported", dev);
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[dev]) {
-        unsigned* ptr = nullptr;
-        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
-        if (!ptr) return fail(GLV_ERR_HIP, "hipGetSymbolAddress returned a null address");
-        g_scratch_ptr[dev] = ptr;
+    unsigned* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        ptr = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (!ptr) {
+            HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+            if (!ptr) return fail(GLV_ERR_HIP, "hipGetSymbolAddress returned a null address");
+            g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+        }
     }
-    *out = g_scratch_ptr[dev];
+    *out = ptr;
     return GLV_OK;
 }
 }  // namespace
+
+// glv_plan_create resolves the address for its device, so that a process that holds a plan can
+// make even its first glv_peak_normalize_noalloc call under stream capture
+static int noalloc_warm_up_current_device() {
+    unsigned* unused = nullptr;
+    return scratch_for_current_device(&unused);
+}
 
 extern "C" int glv_peak_normalize_noalloc(float* y_dev, const int* n_samples_dev, int batch, int64_t y_stride,
                                           float eps, void* stream) {

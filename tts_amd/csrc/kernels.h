@@ -367,6 +367,18 @@ __global__ void init_native_kernel(ElemArgs ea, const float* S_nat, const cf* ph
     }
 }
 
+// the phasors a call without an initial phase draws, written out in caller order (B, T, F)
+__global__ void drawn_phase_kernel(ElemArgs ea, uint64_t seed, cf* out) {
+    const int F = ea.L.F;
+    const int64_t total = (int64_t)ea.batch * ea.L.frames_stride * F;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % F);
+        const int64_t fr = i / F;
+        out[i] = drawn_phase(ea.L, seed, (int)(fr / ea.L.frames_stride), (int)(fr % ea.L.frames_stride), k);
+    }
+}
+
 template <int A, bool TO_NATIVE>
 __global__ void spec_convert_kernel(ElemArgs ea, const cf* src, float inv_n, cf* dst) {
     const int P = ea.L.P;
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(ElemArgs ea, const float*
                                                        const float* iwss_head, const float* iwss_tail,
                                                        const float* iwss_small, float* out, int64_t out_stride,
                                                        int64_t n_begin, unsigned* peak_bits) {
-    // samples [n_begin, n_begin + out_stride) of every row; pointers of a time shard are
-    // pre-shifted so that global sample / block indices address them.  With peak_bits the
+    // samples [n_begin, n_begin + out_stride) of every row (a time shard: its buffers start at
+    // block L.block_origin, `out` at sample L.out_origin of the waveform).  With peak_bits the
     // row maximum of |y| is gathered on the way (one atomic per block, see peak_reduce_kernel).
     __shared__ float wave_max[4];
     const int b = blockIdx.y;

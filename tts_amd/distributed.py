@@ -13,6 +13,9 @@ single-GPU entry points.
 """
 from __future__ import annotations
 
+import inspect
+import socket
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -63,12 +66,26 @@ def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=
     and is cut into runs by a rule that depends on its own length only, so the waveforms are
     bit-identical for every world size, 1 included.
 
+    `gather_dst` is a rank of `group` (not a global rank).  `frames_per_run=None` leaves the run
+    table to the library (fitted to each rank's batch: faster for small shards, but run boundaries
+    then depend on the world size and results agree to rounding only).
+
+    `compute_fn(mels, mean, std, **kw) -> (audio (rows, samples), ...)` replaces the default
+    (`griffin_lim_batch`); of the keywords `utt_ids`, `seed` and `frames_per_run` it is handed
+    those its signature accepts (all of them if it takes **kwargs).
+
     Returns on the gathering rank (or on every rank if it is not distributed) a list of
     1-D arrays in the order of `mels` - numpy, or with `return_tensors` views of the gathered
     tensors where they are; on other ranks, or with `gather_dst=None`, a dict
     {global index: 1-D array} of the local results.
     """
     compute_fn = compute_fn or _default_compute
+    params = inspect.signature(compute_fn).parameters
+    takes_any = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+    def identity_kw(part):
+        extra = {"utt_ids": list(part), "seed": seed, "frames_per_run": frames_per_run}
+        return {k: v for k, v in extra.items() if takes_any or k in params}
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
@@ -97,8 +114,7 @@ def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=
         part = piece(mine, c)
         audio = None
         if part:
-            audio = compute_fn([mels[i] for i in part], mean, std, utt_ids=list(part), seed=seed,
-                               frames_per_run=frames_per_run, **kw)[0]
+            audio = compute_fn([mels[i] for i in part], mean, std, **identity_kw(part), **kw)[0]
             audio = audio.detach() if isinstance(audio, torch.Tensor) else torch.from_numpy(np.asarray(audio))
             for r, i in enumerate(part):
                 local[i] = audio[r, : n_out[i]]
@@ -114,7 +130,9 @@ def synthesize_sharded(mels, mean, std, *, group=None, gather_dst=0, compute_fn=
             block[: audio.shape[0], : audio.shape[1]] = audio[:, :max_len].to(where)
         parts = [torch.empty_like(block) for _ in range(world)] if rank == gather_dst else None
         # asynchronous: the transfer waits for this piece on the device and runs beside the next one
-        work = dist.gather(block, parts, dst=gather_dst, group=group, async_op=True)
+        # (dist.gather names its destination by global rank)
+        dst = dist.get_global_rank(group, gather_dst) if group is not None else gather_dst
+        work = dist.gather(block, parts, dst=dst, group=group, async_op=True)
         pending.append((c, block, parts, work))
     if not distributed:
         return [finish(local[i]) for i in range(len(mels))]
@@ -188,6 +206,18 @@ def _all_reduce_max(x, group):
 _HALO_CHAINS = {}
 
 
+def _check_one_gpu_per_rank(group, world, device):
+    """Raises unless every rank of the group holds a different GPU (collective)."""
+    props = torch.cuda.get_device_properties(device)
+    # the uuid survives a per-process device mask; the index is the fallback
+    mine = (socket.gethostname(), str(getattr(props, "uuid", int(device.index or 0))))
+    seen = [None] * world
+    dist.all_gather_object(seen, mine, group=group)
+    if len(set(seen)) != world:
+        raise RuntimeError("transport='library' needs one GPU per rank: several ranks of this group share a "
+                           "device (use transport='torch')")
+
+
 def _halo_chain(group, rank, world, device):
     """The library-side communicator of `group` on this device: made on first use (collective:
     rank 0's id travels through the group), then kept for the life of the process."""
@@ -214,11 +244,12 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
     samples with each neighbour once per iteration (61 swaps for 60 iterations).  The peak
     for the final normalisation is one all-reduce(MAX) of one float.
 
-    `transport`: "library" - the swap is RCCL send / recv issued by libglvoc itself on the
-    compute stream (glv_halo_create / glv_shard_exchange; the communicator is made once per
-    group from an id that rank 0 broadcasts through it); "torch" - torch.distributed point-to-point on
-    views of the plan's workspace.  Default: "library" when the group's backend is RCCL and
-    every rank has a GPU of its own, else "torch".
+    `transport`: "torch" (the default) - torch.distributed point-to-point on views of the plan's
+    workspace; "library" - the swap is RCCL send / recv issued by libglvoc itself on the compute
+    stream (glv_halo_create / glv_shard_exchange; a second communicator beside torch's, made once
+    per group from an id that rank 0 broadcasts through it).  "library" needs the RCCL backend and
+    a GPU of its own for every rank (checked; two ranks on one GPU cannot join one communicator)
+    and has so far only run with a single rank talking to itself, so it is opt-in.
 
     Returns (y_local, n_begin): a float32 device tensor with this rank's samples
     [n_begin, n_begin + len(y_local)) of the waveform.
@@ -239,10 +270,13 @@ def griffin_lim_time_sharded(mel_db, mean, std, sr=22050, n_fft=1024, hop_length
 
     on_device = dist.get_backend(group) == "nccl"
     if transport is None:
-        transport = "library" if on_device else "torch"
+        transport = "torch"
     if transport not in ("library", "torch"):
         raise ValueError("transport must be 'library' or 'torch'")
     if transport == "library":
+        if not on_device:
+            raise ValueError("transport='library' needs the RCCL ('nccl') backend")
+        _check_one_gpu_per_rank(group, world, plan.device)
         plan.halo_attach(_halo_chain(group, rank, world, plan.device))
 
     def swap():

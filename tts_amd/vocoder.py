@@ -13,6 +13,7 @@ device memory and the stream.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import sys
 import threading
@@ -116,6 +117,8 @@ class GriffinLimPlan:
                                             self.max_batch, self.device.index))
         self._handle = handle
         self._basis_key = None
+        self._options = {}
+        self._utt_ids = None
 
     def close(self):
         if self._handle is not None:
@@ -131,6 +134,20 @@ class GriffinLimPlan:
     # -- configuration -------------------------------------------------------
     def set_option(self, name, value):
         _lib.check(self.lib.glv_plan_set_option(self._handle, name.encode(), int(value)))
+        self._options[name] = int(value)
+
+    @contextlib.contextmanager
+    def call_state(self, utt_ids, frames_per_run):
+        """Utterance identities and run length for the calls inside the block only: what the plan
+        held before (a user's own set_utterance_ids / set_option on a shared plan) is put back."""
+        old_ids, old_fpr = self._utt_ids, self._options.get("frames_per_run", 0)
+        self.set_utterance_ids(utt_ids)
+        self.set_option("frames_per_run", 0 if frames_per_run is None else int(frames_per_run))
+        try:
+            yield self
+        finally:
+            self.set_utterance_ids(old_ids)
+            self.set_option("frames_per_run", old_fpr)
 
     @property
     def workspace_bytes(self):
@@ -147,8 +164,10 @@ class GriffinLimPlan:
         draws the stream (seed, ids[b]).  None = identify utterances by their row."""
         if ids is None:
             _lib.check(self.lib.glv_plan_set_utterance_ids(self._handle, None, 0, _stream_ptr(self.device)))
+            self._utt_ids = None
             return
         arr = np.ascontiguousarray(ids, dtype=np.int64)
+        self._utt_ids = arr
         _lib.check(self.lib.glv_plan_set_utterance_ids(
             self._handle, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), int(arr.shape[0]),
             _stream_ptr(self.device)))
@@ -157,6 +176,15 @@ class GriffinLimPlan:
         ms = ctypes.c_float()
         _lib.check(self.lib.glv_plan_last_loop_ms(self._handle, ctypes.byref(ms)))
         return float(ms.value)
+
+    def drawn_phase(self, seed, batch, frames, frame_origin=0):
+        """(batch, frames, F, 2) unit phasors: the initial phase a call with ``phase0=None`` and this
+        ``seed`` draws on the device for the utterance identities in place (a checking aid: feed
+        them to another implementation to compare a device-drawn call element by element)."""
+        out = torch.empty((int(batch), int(frames), self.n_bins, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.glv_plan_drawn_phase(self._handle, int(seed) & (2**64 - 1), int(batch), int(frames),
+                                                 int(frame_origin), _ptr(out), _stream_ptr(self.device)))
+        return out
 
     def set_inverse_basis(self, pinv):
         pinv = np.ascontiguousarray(pinv, dtype=np.float32)
@@ -536,8 +564,6 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
     frames = mel.shape[0]
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, 0.0, fmax)
-    plan.set_utterance_ids(None)
-    plan.set_option("frames_per_run", 0)
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
     if init_phase is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
@@ -545,13 +571,14 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
     else:
         seed = 0
         phase0 = _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
-    if inversion == "pinv":
-        y = plan.mel_to_audio(mel, mean, std, [frames], phase0=phase0, seed=seed, n_iter=n_iter,
-                              momentum=momentum)
-    else:
-        S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
-        y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)
-        plan.peak_normalize(y)
+    with plan.call_state(None, None):
+        if inversion == "pinv":
+            y = plan.mel_to_audio(mel, mean, std, [frames], phase0=phase0, seed=seed, n_iter=n_iter,
+                                  momentum=momentum)
+        else:
+            S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
+            y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)
+            plan.peak_normalize(y)
     audio = y[0]
     if verbose:
         host = audio.cpu().numpy()
@@ -598,24 +625,25 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
     b, t_max, _ = mel.shape
     if lengths is None:
         lengths = [t_max] * b
+    if utt_ids is not None and len(utt_ids) != b:
+        raise ValueError(f"utt_ids must have one entry per utterance ({b}), got {len(utt_ids)}")
     plan = get_plan(n_fft, hop_length, win_length, n_mels, t_max, b, device)
     plan.set_mel_basis(sr, 0.0, fmax)
-    plan.set_utterance_ids(utt_ids)
-    plan.set_option("frames_per_run", 0 if frames_per_run is None else int(frames_per_run))
     mel = mel.to(device=plan.device, dtype=torch.float32).contiguous()
     n_samples = [hop_length * (int(n) - 1) for n in lengths]
-    if inversion == "pinv":
-        res = plan.mel_to_audio(mel, mean, std, lengths, phase0=phase0, seed=seed, n_iter=n_iter,
-                                momentum=momentum, peak_eps=1e-6 if normalize else None,
-                                return_sc=return_sc)
-        y, sc = res if return_sc else (res, None)
-    else:
-        S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
-        res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
-                              return_sc=return_sc)
-        y, sc = res if return_sc else (res, None)
-        if normalize:
-            plan.peak_normalize(y, n_samples)
+    with plan.call_state(utt_ids, frames_per_run):
+        if inversion == "pinv":
+            res = plan.mel_to_audio(mel, mean, std, lengths, phase0=phase0, seed=seed, n_iter=n_iter,
+                                    momentum=momentum, peak_eps=1e-6 if normalize else None,
+                                    return_sc=return_sc)
+            y, sc = res if return_sc else (res, None)
+        else:
+            S = _invert_mel(plan, mel, mean, std, inversion, nnls_steps)
+            res = plan.griffinlim(S, lengths, phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum,
+                                  return_sc=return_sc)
+            y, sc = res if return_sc else (res, None)
+            if normalize:
+                plan.peak_normalize(y, n_samples)
     return (y, n_samples, sc) if return_sc else (y, n_samples)
 
 
@@ -637,15 +665,14 @@ def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_len
     hop_length = win_length // 4 if hop_length is None else hop_length
     plan = get_plan(n_fft, hop_length, win_length, n_mels, frames, 1, device)
     plan.set_mel_basis(sr, fmin, fmax)
-    plan.set_utterance_ids(None)
-    plan.set_option("frames_per_run", 0)
     mel_tm = mel.t().to(device=plan.device, dtype=torch.float32).contiguous().unsqueeze(0)
     S = plan.mel_invert_nnls(mel_tm, n_steps=n_steps, power=power)
     if init_phase is None:
         seed, phase0 = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]), None
     else:
         seed, phase0 = 0, _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
-    y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)[0]
+    with plan.call_state(None, None):
+        y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)[0]
     return y if return_tensor else y.cpu().numpy()
 
 
