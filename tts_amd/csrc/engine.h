@@ -91,7 +91,11 @@ enum Mode {
     MODE_ITER1 = 6,
     MODE_ISTFT1 = 7,
     MODE_ITER_LIN = 8,
-    MODE_ITER_LIN_Z = 9
+    MODE_ITER_LIN_Z = 9,
+    // the memory operations of MODE_ITER_LIN / MODE_ITER_LIN_Z with the transforms removed (a
+    // measurement aid like MODE_TRAFFIC: the memory-system ceiling of the default iteration)
+    MODE_TRAFFIC_LIN = 10,
+    MODE_TRAFFIC_LIN_Z = 11
 };
 
 struct IterArgs {
@@ -897,6 +901,19 @@ struct Engine {
         shift_rows(acc);
     }
 
+    // ---- MODE_TRAFFIC_LIN(_Z): a frame of the time-domain-momentum iteration without its
+    // arithmetic - magnitudes and the newest block of both signals in, one block out, boundary
+    // blocks shared / deposited as the real kernel does; every loaded value is used once ----
+    template <int NZH>
+    GLV_HD void traffic_frame_lin(const IterArgs& a, int t, const cf* xb) {
+        lin_advance<false>(a, t);
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = cf{raw[r].x + s_n[r], raw[r].y + s_nyq_n + s_mid_n};
+        lin_shift<false>();
+        prefetch_s_pair<NZH>(a, t + 1);
+        ph6<false>(a, t, xb);
+    }
+
     // ---- phase 3 (iSTFT only): the frame to invert is already in `spec` ----
     GLV_HD void ph3_load(const IterArgs& a, int t) {
         if (a.draw)
@@ -950,8 +967,9 @@ struct Engine {
     GLV_HD void ph5_write(cf* w) { F::inv_b_store(v, w, lane); }
 
     // ---- phase 6: last inverse pass, window, overlap-add, emit block t ----
+    template <bool TRANSFORM = true>
     GLV_HD void ph6(const IterArgs& a, int t, const cf* r) {
-        F::inv_a(v, tab, r, lane, twa_regs());
+        if (TRANSFORM) F::inv_a(v, tab, r, lane, twa_regs());
         cf wtab[E];
         load_window(wtab);
 #pragma unroll

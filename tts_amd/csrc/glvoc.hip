@@ -227,6 +227,10 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, false>), g, b, lds, st, a);
+    } else if (mode == MODE_TRAFFIC_LIN) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC_LIN, false>), g, b, lds, st, a);
+    } else if (mode == MODE_TRAFFIC_LIN_Z) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC_LIN_Z, false>), g, b, lds, st, a);
     } else if (mode == MODE_ISTFT1) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ISTFT1, false>), g, b, lds, st, a);
     } else {
@@ -965,7 +969,10 @@ int pair_nzh(const glv_plan* p, bool magnitudes_from_basis) {
 // of the overlap-add generation the final iteration wrote
 // the loop rotates three signal generations (instead of two) in the variants that read the
 // previous signal
-bool three_generations(const glv_plan* p) { return !p->traffic_only && (p->recompute || p->linear); }
+// (the traffic-only stand-in of the time-domain-momentum iteration included; the older
+// traffic-only kernel, "linear" off, moves the spectrum state between two generations)
+bool lin_form(const glv_plan* p) { return p->linear && !p->recompute; }
+bool three_generations(const glv_plan* p) { return lin_form(p) || (p->recompute && !p->traffic_only); }
 
 // one-frame-per-wave modes: generation g of the R partial-sum buffers
 void set_parts_io(const glv_plan* p, IterArgs& a, int in, int out) {
@@ -995,8 +1002,10 @@ int enqueue_loop(glv_plan* p, int frames_stride, int n_iter, float cmom, bool wi
             set_io(p, a, cur, out);
             a.y_prev = p->d_ym[prev];
             a.y_prev_tail = p->d_yt[prev];
-            HIP_TRY(p->launch_engine(p->cur_nzh == 4 * p->A ? MODE_ITER_LIN : MODE_ITER_LIN_Z, with_sc, a,
-                                     engine_grid(p), st));
+            const bool all_bins = p->cur_nzh == 4 * p->A;
+            const int mode = p->traffic_only ? (all_bins ? MODE_TRAFFIC_LIN : MODE_TRAFFIC_LIN_Z)
+                                             : (all_bins ? MODE_ITER_LIN : MODE_ITER_LIN_Z);
+            HIP_TRY(p->launch_engine(mode, with_sc && !p->traffic_only, a, engine_grid(p), st));
             cur = out;
         } else if (p->recompute && !p->traffic_only) {
             // three generations rotate: read `cur` (and the one before it), write the next

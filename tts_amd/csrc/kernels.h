@@ -90,9 +90,10 @@ gl_engine_kernel(IterArgs a) {
     // Kernels that can complete run boundaries on the producer's side.  They keep every table in
     // registers (the default iteration kernels have the room anyway), so that after the set-up
     // the table region of LDS is free to hold the deposits.
-    constexpr bool kCanDeposit = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ISTFT) && !SC &&
-                                 A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
-    using Eng = Engine<A, HB, ((MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC) || kCanDeposit>;
+    constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN ||
+                          MODE == MODE_TRAFFIC_LIN_Z;
+    constexpr bool kCanDeposit = (kLin || MODE == MODE_ISTFT) && !SC && A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
+    using Eng = Engine<A, HB, (kLin && !SC) || kCanDeposit>;
     static_assert(!kCanDeposit || (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= G::TABLES,
                   "the deposits of a workgroup must fit the table region");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,8 +128,7 @@ gl_engine_kernel(IterArgs a) {
     const int ri = blockIdx.x * kWavesPerBlock + wave;
     // kernels whose waves hand boundary blocks to each other through LDS meet at a barrier after
     // the preload: there a wave without a run has to stay until then
-    constexpr bool kShare = (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z) && !SC && A == 1 &&
-                            GLV_SHARE_BOUNDARY;
+    constexpr bool kShare = kLin && !SC && A == 1 && GLV_SHARE_BOUNDARY;
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
     if (!live) {
@@ -192,9 +192,8 @@ gl_engine_kernel(IterArgs a) {
         e.ph6_single(a, t, xb);
         GLV_STAMP(3)
     }
-    constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z;
     // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
-    constexpr int kNzh = MODE == MODE_ITER_LIN_Z ? Eng::NP / 2 : Eng::NP;
+    constexpr int kNzh = (MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN_Z) ? Eng::NP / 2 : Eng::NP;
     if (!kSingle && !kLin && MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
@@ -240,6 +239,10 @@ gl_engine_kernel(IterArgs a) {
         GLV_STAMP(4 + t - e.run.t_begin)
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
+            continue;
+        }
+        if (MODE == MODE_TRAFFIC_LIN || MODE == MODE_TRAFFIC_LIN_Z) {
+            e.template traffic_frame_lin<kNzh>(a, t, xb);
             continue;
         }
         if (MODE == MODE_ITER_RC) {
