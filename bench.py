@@ -170,6 +170,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, choices=[1, 3, 4], default=1,
                     help="1: 64 utterances per GPU (weak scaling); 3: 4096 utterances over all GPUs + final gather; "
                          "4: one 10-minute mel sharded along time, halo swap per iteration")
+    ap.add_argument("--no-persistent", action="store_true",
+                    help="one launch per iteration instead of the iteration-spanning launch")
     ap.add_argument("--rehearse", action="store_true",
                     help="every rank on GPU 0, collectives over gloo: runs the multi-rank paths on a one-GPU machine")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-started run (0: a free one)")
@@ -242,6 +244,8 @@ def variant_name(args, fpr):
         variant += "_unfused"
     if args.inversion != "pinv":
         variant += "_" + args.inversion
+    if args.no_persistent:
+        variant += "_nopersist"
     if args.no_graph:
         variant += "_nograph"
     if args.config == 4:
@@ -363,6 +367,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the rank environment says WORLD_SIZE={world}")
     device = torch.device("cuda", 0 if args.rehearse else local_rank)
     torch.cuda.set_device(device)
+    if args.rehearse and world > 1:
+        # ranks that share a GPU: no launch that needs the device to itself (read at plan creation)
+        os.environ["GLVOC_PERSISTENT"] = "0"
+    if args.no_persistent:
+        os.environ["GLVOC_PERSISTENT"] = "0"
     # GLV_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, barrier, all-reduce,
     # gather) with any world size, to rehearse it under torchrun --nproc-per-node 1
     use_dist = world > 1 or bool(os.environ.get("GLV_BENCH_FORCE_DIST"))
@@ -567,6 +576,7 @@ def main():
                 torch.cuda.synchronize(device)
                 nnls_ms.append(ev[0].elapsed_time(ev[1]))
         finite = bool(torch.isfinite(out).all())
+        plan.status()  # raises if a wait inside an iteration-spanning launch ran out
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if on_device else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -585,7 +595,14 @@ def main():
         s_floats = magnitudes_per_frame(N_FFT, not nnls and not args.unfused and not config4)
         fused_bytes = fused_bytes_per_launch(N_FFT, frames_list, s_floats)
         unfused_bytes = sum(44 * f_bins * t + 8 * HOP * (t - 1) for t in frames_list)
-        kernel_ms = float(np.mean(loop_ms)) / N_ITER
+        # the loop is one iteration-spanning launch where the library could make it one (every run
+        # resident at once), else one launch per iteration: bytes and time are those of a LAUNCH
+        launches = 1 if config4 else max(1, plan.last_loop_launches())
+        iters_per_launch = 1 if config4 else N_ITER // launches
+        iter_ms = float(np.mean(loop_ms)) / N_ITER
+        kernel_ms = iter_ms * iters_per_launch
+        iter_bytes, iter_unfused = fused_bytes, unfused_bytes
+        fused_bytes, unfused_bytes = fused_bytes * iters_per_launch, unfused_bytes * iters_per_launch
         achieved = fused_bytes / (kernel_ms * 1e-3) / 1e9
         key = traffic_key(N_FFT, HOP, batch, args.frames, args.lengths, variant_name(args, fpr))
         traffic, traffic_source = measured_traffic(key)
@@ -625,13 +642,20 @@ def main():
                        "parallelism": (f"time-sharded x{world}, point-to-point halo swap per iteration" if config4 else
                                        f"batch-sharded x{world}, final device-side gather" if config3 else
                                        f"batch-sharded x{world}, no data-path collective")},
-            "roofline": {"bound": "hbm", "kernel": f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration>",
+            "roofline": {"bound": "hbm",
+                         "kernel": (f"gl_persist_kernel<n_fft {N_FFT}, hop {HOP}> (all {N_ITER} iterations in one launch)"
+                                    if iters_per_launch > 1 else
+                                    f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration>"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "bytes_model": f"fused iteration: T*(4*{s_floats} + 12H) + (R-1)*12H per utterance and launch "
-                                        f"({s_floats} magnitudes per frame, P = {p_half})",
+                         "bytes_model": f"fused iteration: T*(4*{s_floats} + 12H) + (R-1)*12H per utterance and iteration "
+                                        f"({s_floats} magnitudes per frame, P = {p_half}), x {iters_per_launch} "
+                                        f"iteration(s) per launch",
                          "alg_bytes_per_launch": fused_bytes,
                          "kernel_ms_per_launch": round(kernel_ms, 5),
+                         "iterations_per_launch": iters_per_launch,
+                         "alg_bytes_per_iteration": iter_bytes,
+                         "kernel_ms_per_iteration": round(iter_ms, 5),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_key": key, "engine_source_digest": engine_source_digest(),
                          # measured HBM bytes per launch over the same time

@@ -339,13 +339,37 @@ int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
  *                        "nnls_fused" (1/0, default 1: all steps of glv_mel_invert_nnls in one launch
  *                        with the solution resident in registers; 0 = two launches per step),
  *                        "traffic_only" (0/1: measurement aid - the iteration kernels issue
- *                        their loads and stores but skip the arithmetic; output is garbage).
+ *                        their loads and stores but skip the arithmetic; output is garbage),
+ *                        "persistent" (1/0, default 1: with "linear" on and no convergence curve, a call
+ *                        whose runs fit the device's wave slots at once runs ALL its iterations in one
+ *                        launch - a wave keeps its run, and runs whose boundary blocks travel through
+ *                        memory wait for their neighbours' progress words - instead of one launch per
+ *                        iteration; same bits.  It needs the device to itself: if other work keeps
+ *                        part of the launch from being resident the waits run out after a fraction
+ *                        of a second, see glv_plan_status; set 0 where processes share a device - the
+ *                        environment variable GLVOC_PERSISTENT=0 does so for every plan of a process.
+ *                        2 = also for calls too large to be resident at once: a test aid that makes
+ *                        the waits run out).
  *   glv_plan_last_loop_ms: with "timing" on, milliseconds the n_iter iteration
  *                        kernels of the last glv_griffinlim call took on the
  *                        stream (synchronises on the closing event).
  */
 int glv_plan_set_option(glv_plan* plan, const char* name, int value);
 int glv_plan_last_loop_ms(glv_plan* plan, float* ms_out);
+/*
+ * GLV_OK, or GLV_ERR_STATE once a wait inside a "persistent" launch has run out (the launch was
+ * not resident as a whole): the results of that call are void, and the plan launches every
+ * iteration separately from then on.  Reads a host word the device raises; does not synchronise,
+ * so ask after the stream has been waited for.  No counterpart in the reference.
+ *   glv_plan_persistent_capacity: workgroups of the iteration-spanning kernel (variant 0: all
+ *   bins, 1: zero-for-good bins left out) that glv_plan_create saw resident together; calls with
+ *   at most that many workgroups (4 runs each) use it.
+ */
+int glv_plan_status(glv_plan* plan);
+int glv_plan_persistent_capacity(const glv_plan* plan, int variant);
+/* Kernel launches the iteration loop of the last Griffin-Lim call took: 1 when it ran as one
+ * iteration-spanning launch, n_iter otherwise. */
+int glv_plan_last_loop_launches(const glv_plan* plan);
 
 /*
  * Writes the initial phase the library draws when a call passes phase0_dev == NULL: the unit

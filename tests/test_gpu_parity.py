@@ -831,7 +831,8 @@ def test_time_sharded_two_processes(n_fft, hop, frames, world, backend):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    # several processes share the one GPU here: no launch that needs the device to itself
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLVOC_PERSISTENT="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
            os.path.join(here, "time_shard_worker.py"), str(n_fft), str(hop), str(frames), backend,
@@ -852,7 +853,8 @@ def test_batch_sharded_processes(backend, world):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    # several processes share the one GPU here: no launch that needs the device to itself
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLVOC_PERSISTENT="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29650 + world),
            os.path.join(here, "batch_shard_worker.py"), backend]
@@ -1222,3 +1224,79 @@ def test_long_form_time_sharded_at_full_size(voc, O, lj001):
     lib_plan.halo_attach(None)
     lib_plan.close()
     chain.close()
+
+
+@pytest.mark.parametrize("hop,win,lens,fpr", [(256, 1024, [430] * 64, 0), (256, 1024, [150, 33, 64, 7, 2, 97], 0),
+                                              (256, 1024, [150, 33, 64, 7, 2, 97], 5), (512, 800, [120, 60, 33], 0),
+                                              (256, 1024, [300] * 16 + [111] * 9, 0)])
+def test_all_iterations_in_one_launch(voc, hop, win, lens, fpr):
+    """Option "persistent" (n_fft 1024): when the runs of a call are resident on the device together,
+    ONE launch carries all iterations - a wave keeps its run, runs whose boundary blocks travel
+    through memory wait for their neighbours' progress words, the blocks behind a run's last frame
+    come from LDS so the frame loop reads no tail buffer.  The same additions in the same order as
+    one launch per iteration: waveforms must be identical bit for bit, from mel input (bins that
+    are zero for good left out) and from caller magnitudes (all bins), with drawn and explicit
+    phases, for 1, 2, 3, 8 and 60 iterations (60: vocoder/mel_audio.py:126) - and the call must
+    really have taken one launch, and no wait may have run out."""
+    n_fft, f = 1024, 513
+    t_max, b = max(lens), len(lens)
+    rng = np.random.default_rng(61)
+    mel = np.stack([np.pad(synthetic_mel(700 + i, t), ((0, t_max - t), (0, 0))) for i, t in enumerate(lens)])
+    s = np.zeros((b, t_max, f), np.float32)
+    p0 = np.zeros((b, t_max, f, 2), np.float32)
+    for i, t in enumerate(lens):
+        s[i, :t] = rng.standard_normal((t, f)) ** 2
+        ang = 2 * np.pi * rng.random((t, f))
+        p0[i, :t, :, 0], p0[i, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, win, 80, t_max, b)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    plan.set_option("single_frame", 0)
+    plan.set_option("frames_per_run", fpr)
+    assert plan.persistent_capacity(0) > 0 and plan.persistent_capacity(1) > 0
+    got = {}
+    for persistent in (1, 0):
+        plan.set_option("persistent", persistent)
+        for k in (1, 2, 3, 8, 60):
+            got[persistent, k, "mel"] = plan.mel_to_audio(dev(mel), MEAN, STD, lens, seed=5, n_iter=k).clone()
+            assert plan.last_loop_launches() == (1 if persistent else k)
+            if k in (2, 8):
+                got[persistent, k, "s"] = plan.griffinlim(dev(s), lens, phase0=dev(p0), n_iter=k).clone()
+                assert plan.last_loop_launches() == (1 if persistent else k)
+    torch.cuda.synchronize()
+    plan.status()
+    for (persistent, k, src), y in got.items():
+        if persistent:
+            assert float(y.abs().max()) > 0
+            assert torch.equal(y, got[0, k, src]), (k, src)
+    plan.close()
+
+
+def test_a_launch_that_is_not_resident_as_a_whole_is_reported(voc):
+    """The iteration-spanning launch needs its workgroups on the device together.  Forced (option
+    "persistent" = 2, a test aid) on ONE long utterance cut into twice as many workgroups as fit,
+    for more iterations than there are resident workgroups in the chain, every resident workgroup
+    ends up waiting for one that is not: the waits run out after a fraction of a second, every wave
+    still ends, the plan's status says that the call's results are void, and the plan goes back to
+    one launch per iteration - whose result is the right one.  (A batch of many utterances in
+    launch order does not get there: utterances that are resident as a whole finish and make
+    room.)"""
+    n_fft, hop, frames = 1024, 256, 30000
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, frames, 1)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    cap = plan.persistent_capacity(1)
+    assert cap > 0
+    n_iter = cap + 40
+    mel = dev(synthetic_mel(800, frames)[None])
+    plan.set_option("run_target", 8 * cap)   # 2 x cap workgroups of 4 runs
+    plan.set_option("persistent", 0)
+    want = plan.mel_to_audio(mel, MEAN, STD, [frames], seed=9, n_iter=n_iter).clone()
+    plan.set_option("persistent", 2)
+    plan.mel_to_audio(mel, MEAN, STD, [frames], seed=9, n_iter=n_iter)
+    assert plan.last_loop_launches() == 1
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="waited in vain"):
+        plan.status()
+    again = plan.mel_to_audio(mel, MEAN, STD, [frames], seed=9, n_iter=n_iter)
+    assert plan.last_loop_launches() == n_iter
+    assert torch.equal(again, want)
+    plan.close()

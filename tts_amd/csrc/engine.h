@@ -95,7 +95,12 @@ enum Mode {
     // the memory operations of MODE_ITER_LIN / MODE_ITER_LIN_Z with the transforms removed (a
     // measurement aid like MODE_TRAFFIC: the memory-system ceiling of the default iteration)
     MODE_TRAFFIC_LIN = 10,
-    MODE_TRAFFIC_LIN_Z = 11
+    MODE_TRAFFIC_LIN_Z = 11,
+    // MODE_ITER_LIN / MODE_ITER_LIN_Z with ALL iterations of a call in one launch: every wave
+    // keeps its run for the whole call and runs whose boundary blocks travel through memory wait
+    // for their neighbours' progress words (see "iteration-spanning" in kernels.h)
+    MODE_ITER_LIN_P = 12,
+    MODE_ITER_LIN_Z_P = 13
 };
 
 struct IterArgs {
@@ -140,7 +145,19 @@ struct IterArgs {
     // Time shard: runs, frames and blocks are numbered over the whole utterance, while spec, S and
     // the overlap-add buffers hold only the shard - index 0 there is frame / block t_origin.
     int t_origin;
+    // Iteration-spanning kernels (MODE_ITER_LIN_P / _Z_P): iteration k reads generation k % 3 of
+    // the overlap-add buffers (and (k + 2) % 3 as the older signal), writes (k + 1) % 3.
+    int n_iter;
+    float* gen_main[3];
+    float* gen_tail[3];
+    int* progress;  // [n_runs] words kProgressStride ints apart, zero at launch: iterations whose
+                    //   boundary blocks the run has written through to memory
+    int* status;    // one word, zero at launch: set when a wait ran out (the results are void then)
+    int* host_status;  // the same in host memory the device can write; never cleared by a launch
+    int census;     // 1: only count the workgroups that are resident together (nothing is computed)
 };
+// distance between two runs' progress words: a word is stored by one wave and polled by at most two
+constexpr int kProgressStride = 32;
 
 // Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
 // again before the whole working set has passed through the caches, so the accesses can be
@@ -178,6 +195,18 @@ __device__ __forceinline__ void st_stream(f4* p, f4 v) {
 #else
 GLV_HD void st_stream(cf* p, cf v) { *p = v; }
 GLV_HD void st_stream(f4* p, f4 v) { *p = v; }
+#endif
+
+// Stores of blocks that waves of OTHER workgroups read later in the same launch (iteration-spanning
+// kernels): written through to memory at device scope, 8 bytes per instruction.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void st_shared(cf* p, cf v) {
+    const unsigned long long bits =
+        ((unsigned long long)__float_as_uint(v.y) << 32) | (unsigned long long)__float_as_uint(v.x);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+GLV_HD void st_shared(cf* p, cf v) { *p = v; }
 #endif
 
 // 1 / (sqrt(x) + tiny) for x >= 0 without the square root: the hardware reciprocal square root
@@ -226,10 +255,14 @@ GLV_HD uint32_t counter_high_part(uint64_t seed, uint32_t idx_high);
 GLV_HD float counter_uniform_low(uint32_t high_part, uint32_t idx_low);
 GLV_HD cf phasor_of(float u);
 
-// TWR: the twiddles of the first and second FFT pass stay in registers for the whole run as
+// TWR = 2: only the first pass's (the second pass's 8 entries per lane are read from LDS; they
+// are the same for lanes 8 apart, so those reads are broadcasts).
+// TWR = 1: the twiddles of the first and second FFT pass stay in registers for the whole run as
 // well (n_fft 1024 only; 26 more registers, 12 fewer 16-byte LDS reads per frame) - for the
 // kernels whose register budget leaves room for them at three waves per SIMD.
-template <int A, int HB, bool TWR = false>
+// NT: the frame loop never reads a tail buffer (iteration-spanning kernels: the blocks whose
+// second half sits there are all taken before the first frame, preload_lin / preload_next).
+template <int A, int HB, int TWR = 0, bool NT = false>
 struct Engine {
     using G = Geo<A>;
     using F = WaveFft<A>;
@@ -276,10 +309,11 @@ struct Engine {
     // the FFT pass twiddles as well (TWR): 26 more registers, which the time-domain-momentum
     // kernels can afford at three waves per SIMD (38.7 against 39.9 us per launch) and the
     // others cannot (GLV_TWIDDLES_IN_REGS forces them on everywhere, for experiments)
-    static constexpr bool kRegTw = kRegTab && (TWR || GLV_TWIDDLES_IN_REGS);
+    static constexpr bool kRegTw = kRegTab && (TWR != 0 || GLV_TWIDDLES_IN_REGS);
     // n_fft 2048: only the second pass's (one set serves both sub-sequences; 249 of the 256
     // registers two waves per SIMD can have, 148.3 -> 146.5 us per launch)
-    static constexpr bool kRegTwB = kRegTw || (A == 2 && TWR && GLV_TWB_IN_REGS_A2);
+    static constexpr bool kRegTwB =
+        (kRegTab && (TWR == 1 || GLV_TWIDDLES_IN_REGS)) || (A == 2 && TWR == 1 && GLV_TWB_IN_REGS_A2);
     cf twa_r[kRegTw ? 8 : 1];
     cf twb_r[kRegTwB ? 8 : 1];
     GLV_HD const cf* twa_regs() const { return kRegTw ? twa_r : nullptr; }
@@ -305,6 +339,8 @@ struct Engine {
         share_next = nullptr;
         deposit_out = nullptr;
         deposit_in = nullptr;
+        heads_shared = false;
+        tails_shared = false;
         tab.twA = tables;
         tab.twB = tab.twA + G::TW_A;
         tab.twC = tab.twB + G::TW_B;
@@ -341,6 +377,11 @@ struct Engine {
         for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
         sc_num = 0.f;
         sc_den = 0.f;
+    }
+    // a further iteration over the same run (iteration-spanning kernels): the running sum restarts
+    GLV_HD void begin_iteration() {
+#pragma unroll
+        for (int r2 = 0; r2 < E; ++r2) acc[r2] = cf{0.f, 0.f};
     }
 
     // Block j of the previous iteration's signal is (main + tail) / wss, and zero outside
@@ -382,6 +423,10 @@ struct Engine {
     // two.  head + tail in that order, as the reader adds them: the same bits.
     cf* deposit_out = nullptr;       // this run's first R-1 blocks go here, not to memory
     const cf* deposit_in = nullptr;  // the next run's deposit: completes this run's last R-1 blocks
+    // Iteration-spanning kernels: the previous / next run reads this run's first R-1 blocks / its
+    // tail sums from memory within the same launch, so those stores are written through (st_shared)
+    bool heads_shared = false;
+    bool tails_shared = false;
     GLV_HD bool from_next(int j) const { return share_next != nullptr && j >= run.t_end; }
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1 + block_extra; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
@@ -421,6 +466,17 @@ struct Engine {
                 const cf val = f.main[k] + f.tail[k];
                 const float wx = a.raw_in ? 1.0f : w[k].x, wy = a.raw_in ? 1.0f : w[k].y;
                 dst[row0 + i + 8 * s2] = cf{val.x * wx, val.y * wy};
+            }
+    }
+    // the same for a block fetched without its tail half (frame loop of the NT engines)
+    GLV_HD void finish_block_nt(const IterArgs& a, const BlockFetch& f, const cf (&w)[HV], cf (&dst)[E],
+                                int row0) const {
+#pragma unroll
+        for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int k = i + HB * s2;
+                dst[row0 + i + 8 * s2] = cf{f.main[k].x * w[k].x, f.main[k].y * w[k].y};
             }
     }
     GLV_HD void load_block(const IterArgs& a, const float* y_main, const float* y_tail, int j,
@@ -465,10 +521,10 @@ struct Engine {
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
             load_row(pm, i, blk_n.main);
-            load_row(pt, i, blk_n.tail);
+            if (!NT) load_row(pt, i, blk_n.tail);
             load_row(pw, i, blk_n.w);
             load_row(pmp, i, blkp_n.main);
-            load_row(ptp, i, blkp_n.tail);
+            if (!NT) load_row(ptp, i, blkp_n.tail);
         }
     }
     // ... and its previous spectrum and target magnitudes
@@ -492,15 +548,27 @@ struct Engine {
     }
 
     // rows row0 .. row0+HB-1 of a time-side register array -> block j
+    // (SHARED: another workgroup reads the block within this launch, see st_shared)
+    template <bool SHARED = false>
     GLV_HD void store_block(const IterArgs& a, float* dst, int j, const cf (&src)[E], int row0) const {
         float* p = block_valid(j) ? dst + (int64_t)run.utt * a.y_utt_stride + (int64_t)(j - a.t_origin) * H : a.trash;
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
             if (A == 1) {
-                st_stream(reinterpret_cast<cf*>(p + ROW * i + 2 * lane), src[row0 + i]);
+                cf* q = reinterpret_cast<cf*>(p + ROW * i + 2 * lane);
+                if (SHARED)
+                    st_shared(q, src[row0 + i]);
+                else
+                    st_stream(q, src[row0 + i]);
             } else {
                 const cf lo = src[row0 + i], hi = src[row0 + i + 8 * (A - 1)];
-                st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
+                if (SHARED) {
+                    cf* q = reinterpret_cast<cf*>(p + ROW * i + 4 * lane);
+                    st_shared(q, lo);
+                    st_shared(q + 1, hi);
+                } else {
+                    st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
+                }
             }
         }
     }
@@ -548,6 +616,17 @@ struct Engine {
             load_block(a, a.y_prev, a.y_prev_tail, run.t_begin + q, v, q * HB);
         }
         combine_rows<SC, 0, (R - 1) * HB>(c);
+        if (NT && share_next != nullptr) {
+            // an utterance shorter than R-1 frames: some of these blocks lie behind the run's last
+            // frame, were fetched as zeros and come from the LDS slot like the later ones
+#pragma unroll
+            for (int q = 0; q < R - 1; ++q)
+                if (run.t_begin + q >= run.t_end) {
+#pragma unroll
+                    for (int i = 0; i < HB; ++i)
+                        raw[q * HB + i] = raw[q * HB + i] + share_next[((run.t_begin + q - run.t_end) * HB + i) * (ROW / 2) + lane];
+                }
+        }
     }
     // rows [row0, row1) of every sub-sequence: raw = y_k - c * y_{k-1} (y_{k-1} sits in v)
     template <bool SC, int ROW0, int ROW1>
@@ -564,8 +643,13 @@ struct Engine {
     // newest block of both signals into the windows, loads for the next frame issued
     template <bool SC>
     GLV_HD void lin_advance(const IterArgs& a, int t) {
-        finish_block(a, blk_n, raw, (R - 1) * HB);
-        finish_block_w(a, blkp_n, blk_n.w, v, (R - 1) * HB);
+        if (NT) {
+            finish_block_nt(a, blk_n, blk_n.w, raw, (R - 1) * HB);
+            finish_block_nt(a, blkp_n, blk_n.w, v, (R - 1) * HB);
+        } else {
+            finish_block(a, blk_n, raw, (R - 1) * HB);
+            finish_block_w(a, blkp_n, blk_n.w, v, (R - 1) * HB);
+        }
         prefetch_block_pair(a, t + 1);
         combine_rows<SC, (R - 1) * HB, R * HB>(a.has_prev ? a.cmom : 0.0f);
         if (from_next(t + R - 1)) take_shared(t + R - 1 - run.t_end);
@@ -577,6 +661,22 @@ struct Engine {
         static_assert(A == 1, "only the n_fft 1024 kernels share boundary blocks");
 #pragma unroll
         for (int row = 0; row < (R - 1) * HB; ++row) mine[row * (ROW / 2) + lane] = raw[row];
+    }
+    // The R-1 blocks after this run's last frame, combined like a preload (y_k - c y_{k-1}), left in
+    // LDS where take_shared finds them: what the next run's publish_preload would have put there,
+    // made by this run itself because that run is not a wave of this workgroup (or does not
+    // exist).  Both halves of every block are fetched here, so the frame loop needs no tails.
+    // Call before preload_lin (uses the same registers) and before share_next is set.
+    GLV_HD void preload_next(const IterArgs& a, cf* slot) {
+        static_assert(A == 1, "only the n_fft 1024 kernels share boundary blocks");
+        const float c = a.has_prev ? a.cmom : 0.0f;
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) {
+            load_block(a, a.y_in, a.y_in_tail, run.t_end + q, raw, q * HB);
+            load_block(a, a.y_prev, a.y_prev_tail, run.t_end + q, v, q * HB);
+        }
+        combine_rows<false, 0, (R - 1) * HB>(c);
+        publish_preload(slot);
     }
     // block q of the next run's preload = this frame's newest block (the fetch delivered zeros)
     GLV_HD void take_shared(int q) {
@@ -980,6 +1080,8 @@ struct Engine {
         }
         if (deposit_out != nullptr && t < run.t_begin + R - 1)
             deposit_block(t - run.t_begin);
+        else if (heads_shared && t < run.t_begin + R - 1)
+            store_block<true>(a, a.y_out, t, acc, 0);
         else
             store_block(a, a.y_out, t, acc, 0);
         shift_rows(acc);
@@ -1108,6 +1210,11 @@ struct Engine {
                 for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out, run.t_end + q, acc, q * HB);
                 return;
             }
+        }
+        if (tails_shared) {
+#pragma unroll
+            for (int q = 0; q < R - 1; ++q) store_block<true>(a, a.y_out_tail, run.t_end + q, acc, q * HB);
+            return;
         }
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out_tail, run.t_end + q, acc, q * HB);

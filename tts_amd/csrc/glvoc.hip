@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -73,6 +74,15 @@ struct glv_plan {
     int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
                             // with runs, 0 = never, 1 = always
     bool cur_single = false;    // the run table in place is one run per frame
+    // All iterations of a call in ONE launch (MODE_ITER_LIN_P / _Z_P) when the call's workgroups
+    // are resident together: -1 = off for good (a launch timed out), 0 = off, 1 = on.
+    int persistent = 1;         // (2: even when the launch cannot be resident as a whole - a test aid)
+    int last_loop_launches = 0; // kernel launches the iteration loop of the last call took
+    int persist_capacity[2] = {0, 0};  // workgroups seen resident together, per kernel (all bins / zero-skip)
+    int* d_progress = nullptr;         // status word (one stride) followed by the runs' progress words
+    size_t progress_runs = 0;          // runs the progress words are laid out for
+    int* h_status = nullptr;           // pinned, device-visible: raised by a wave whose wait ran out; sticky
+    int* h_status_dev = nullptr;
     int deposit = 1;            // option: run boundaries inside a workgroup completed by the producer
     bool cur_deposit = false;   // the tail flags in place (and the call in progress) follow that convention
     float* d_parts = nullptr;   // 2 generations x R partial-sum buffers (one-frame-per-wave modes)
@@ -170,6 +180,7 @@ struct glv_plan {
     // kernel launchers for this shape
     hipError_t (*launch_engine)(int mode, bool sc, const IterArgs&, size_t grid, hipStream_t) = nullptr;
     int (*engine_blocks_per_cu)() = nullptr;
+    int (*persist_blocks_per_cu)(int variant) = nullptr;
     void (*launch_init)(const ElemArgs&, const float*, const cf*, uint64_t, float, float*, cf*,
                         hipStream_t) = nullptr;
     void (*launch_convert)(bool to_native, const ElemArgs&, const cf*, float, cf*, hipStream_t) = nullptr;
@@ -185,8 +196,8 @@ namespace {
 template <int A, int HB>
 constexpr size_t engine_lds_bytes() {
     using G = Geo<A>;
-    return (size_t)(G::TABLES + kWavesPerBlock * G::XBUF) * sizeof(cf) +
-           (A == 1 ? (size_t)kWavesPerBlock * Engine<A, HB>::kShareFloats * sizeof(float) : 0);
+    return (size_t)(table_span<A, HB>() + kWavesPerBlock * G::XBUF) * sizeof(cf) +
+           (A == 1 ? (size_t)(kWavesPerBlock + 1) * Engine<A, HB>::kShareFloats * sizeof(float) : 0);
 }
 
 template <int A, int HB>
@@ -227,6 +238,15 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_LIN_P || mode == MODE_ITER_LIN_Z_P) {
+        if constexpr (A == 1) {
+            if (mode == MODE_ITER_LIN_P)
+                hipLaunchKernelGGL((gl_persist_kernel<HB, MODE_ITER_LIN_P>), g, b, lds, st, a);
+            else
+                hipLaunchKernelGGL((gl_persist_kernel<HB, MODE_ITER_LIN_Z_P>), g, b, lds, st, a);
+        } else {
+            return hipErrorInvalidDeviceFunction;
+        }
     } else if (mode == MODE_TRAFFIC_LIN) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC_LIN, false>), g, b, lds, st, a);
     } else if (mode == MODE_TRAFFIC_LIN_Z) {
@@ -247,6 +267,23 @@ int engine_blocks_per_cu_t() {
                                                      64 * kWavesPerBlock, lds) != hipSuccess)
         n = 1;
     return n < 1 ? 1 : n;
+}
+// the same for the iteration-spanning kernels (variant 0: all bins, 1: zero-skip)
+template <int A, int HB>
+int persist_blocks_per_cu_t(int variant) {
+    if constexpr (A == 1) {
+        const size_t lds = engine_lds_bytes<A, HB>();
+        int n = 0;
+        const hipError_t e =
+            variant == 0
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_persist_kernel<HB, MODE_ITER_LIN_P>,
+                                                               64 * kWavesPerBlock, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_persist_kernel<HB, MODE_ITER_LIN_Z_P>,
+                                                               64 * kWavesPerBlock, lds);
+        return e == hipSuccess && n > 0 ? n : 0;
+    } else {
+        return 0;  // the iteration-spanning kernels exist for n_fft 1024 only
+    }
 }
 
 inline unsigned grid_for(int64_t total, int block) {
@@ -300,6 +337,7 @@ void bind_launchers(glv_plan* p) {
     p->launch_power = &launch_power_t<A>;
     p->launch_engine = &launch_engine_t<A, HB>;
     p->engine_blocks_per_cu = &engine_blocks_per_cu_t<A, HB>;
+    p->persist_blocks_per_cu = &persist_blocks_per_cu_t<A, HB>;
     p->launch_init = &launch_init_t<A>;
     p->launch_convert = &launch_convert_t<A>;
 }
@@ -337,7 +375,8 @@ void plan_free(glv_plan* p) {
     drop_graphs(p);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    void* dev[] = {p->d_nnls_a1, p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    if (p->h_status) (void)hipHostFree(p->h_status);
+    void* dev[] = {p->d_progress, p->d_nnls_a1, p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial, p->d_utt_ids};
     for (void* q : dev)
@@ -643,7 +682,34 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
                        hipMemcpyHostToDevice));
     PLAN_TRY(hipEventCreate(&p->ev0));
     PLAN_TRY(hipEventCreate(&p->ev1));
+    // iteration-spanning kernels: a status word the device can raise in host memory, progress
+    // words for as many runs as the device can hold at once, and a census of how many of their
+    // workgroups really are resident together (the occupancy query can overstate it)
+    PLAN_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_status), 64, hipHostMallocMapped));
+    p->h_status[0] = 0;
+    PLAN_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->h_status_dev), p->h_status, 0));
+    if (const char* env = getenv("GLVOC_PERSISTENT")) p->persistent = atoi(env) != 0 ? 1 : 0;
+    p->progress_runs = (size_t)p->n_cus * 8 * kWavesPerBlock;
+    PLAN_TRY(dmalloc(p, &p->d_progress, (1 + p->progress_runs) * kProgressStride));
     PLAN_TRY(hipDeviceSynchronize());
+    for (int variant = 0; variant < 2; ++variant) {
+        int per_cu = std::min(8, p->persist_blocks_per_cu(variant));
+        for (; per_cu > 0 && p->persist_capacity[variant] == 0; --per_cu) {
+            const int grid = per_cu * p->n_cus;
+            PLAN_TRY(hipMemset(p->d_progress, 0, (size_t)2 * kProgressStride * sizeof(int)));
+            IterArgs a = iter_args(p, 1);
+            a.census = 1;
+            a.n_iter = 0;
+            a.progress = p->d_progress + kProgressStride;
+            a.status = p->d_progress;
+            a.host_status = p->h_status_dev;
+            PLAN_TRY(p->launch_engine(variant == 0 ? MODE_ITER_LIN_P : MODE_ITER_LIN_Z_P, false, a, (size_t)grid, nullptr));
+            PLAN_TRY(hipDeviceSynchronize());
+            int seen[2] = {0, 0};
+            PLAN_TRY(hipMemcpy(seen, p->d_progress + kProgressStride, sizeof(seen), hipMemcpyDeviceToHost));
+            if (seen[0] == grid && seen[1] == grid) p->persist_capacity[variant] = grid;
+        }
+    }
 #undef PLAN_TRY
     if (noalloc_warm_up_current_device() != GLV_OK) {
         plan_free(p);
@@ -696,6 +762,9 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     } else if (!strcmp(name, "deposit")) {
         p->deposit = value != 0;
         drop_graphs(p);
+    } else if (!strcmp(name, "persistent")) {
+        if (value < 0 || value > 2) return fail(GLV_ERR_INVALID, "persistent must be 0, 1 or 2");
+        if (p->persistent >= 0) p->persistent = value;
     } else if (!strcmp(name, "halo_loopback")) {
         p->halo_loopback = value != 0;
     } else if (!strcmp(name, "fuse_draw")) {
@@ -785,6 +854,24 @@ extern "C" int glv_plan_last_loop_ms(glv_plan* p, float* ms_out) {
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(ms_out, p->ev0, p->ev1));
     return GLV_OK;
+}
+
+extern "C" int glv_plan_status(glv_plan* p) {
+    if (!p) return fail(GLV_ERR_INVALID, "null plan");
+    if (p->h_status && *(volatile int*)p->h_status != 0) {
+        p->persistent = -1;
+        return fail(GLV_ERR_STATE,
+                    "an iteration-spanning launch waited in vain for a neighbouring workgroup (is the device shared "
+                    "with other work?): the results of that call are void; later calls launch every iteration "
+                    "separately");
+    }
+    return GLV_OK;
+}
+
+extern "C" int glv_plan_last_loop_launches(const glv_plan* p) { return p ? p->last_loop_launches : 0; }
+
+extern "C" int glv_plan_persistent_capacity(const glv_plan* p, int variant) {
+    return p && variant >= 0 && variant < 2 ? p->persist_capacity[variant] : 0;
 }
 
 extern "C" int glv_plan_set_inverse_basis(glv_plan* p, const float* pinv_host) {
@@ -1036,6 +1123,36 @@ struct MagnitudeSource {
     float mean = 0.f, std_ = 1.f;
 };
 
+// can this call's loop run as one iteration-spanning launch?  (variant: 0 all bins, 1 zero-skip)
+bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter) {
+    if (p->persistent <= 0 || !lin_runs || with_sc || n_iter < 1) return false;
+    if (p->traffic_only || p->alias_utts || p->recompute || !p->cur_deposit) return false;
+    const int variant = p->cur_nzh == 4 * p->A ? 0 : 1;
+    if ((size_t)p->n_runs > p->progress_runs || p->persist_capacity[variant] <= 0) return false;
+    return p->persistent == 2 || (int64_t)engine_grid(p) <= (int64_t)p->persist_capacity[variant];
+}
+
+// all n_iter iterations as ONE launch: progress words cleared, then the kernel
+int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(p->d_progress, 0, (size_t)(1 + p->n_runs) * kProgressStride * sizeof(int), st));
+    IterArgs a = iter_args(p, frames_stride);
+    a.cmom = cmom;
+    a.n_iter = n_iter;
+    for (int g = 0; g < 3; ++g) {
+        a.gen_main[g] = p->d_ym[g];
+        a.gen_tail[g] = p->d_yt[g];
+    }
+    set_io(p, a, 0, 1);
+    a.y_prev = p->d_ym[0];
+    a.y_prev_tail = p->d_yt[0];
+    a.status = p->d_progress;
+    a.progress = p->d_progress + kProgressStride;
+    a.host_status = p->h_status_dev;
+    const bool all_bins = p->cur_nzh == 4 * p->A;
+    HIP_TRY(p->launch_engine(all_bins ? MODE_ITER_LIN_P : MODE_ITER_LIN_Z_P, false, a, engine_grid(p), st));
+    return GLV_OK;
+}
+
 int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0_dev, uint64_t seed,
                     const int* n_frames_host, int batch, int frames_stride, int n_iter, float momentum,
                     float* y_dev, int64_t y_stride, float* sc_curve_dev, unsigned* peak_bits, void* stream) {
@@ -1130,7 +1247,15 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
 
     const float cmom = momentum / (1.0f + momentum);
     if (p->timing) HIP_TRY(hipEventRecord(p->ev0, st));
-    if (n_iter > 0) {
+    // a wait of an earlier iteration-spanning launch ran out: that call's results were void
+    // (glv_plan_status reports it); from now on the loop is launched one iteration at a time
+    if (p->persistent > 0 && p->h_status && *(volatile int*)p->h_status != 0) p->persistent = -1;
+    p->last_loop_launches = n_iter;
+    if (n_iter > 0 && persistent_fits(p, lin_runs, with_sc, n_iter)) {
+        rc = enqueue_persistent(p, frames_stride, n_iter, cmom, st);
+        if (rc != GLV_OK) return rc;
+        p->last_loop_launches = 1;
+    } else if (n_iter > 0) {
         if (p->use_graph) {
             const glv_plan::GraphKey key{p->n_runs, n_iter, with_sc ? 1 : 0, frames_stride, batch,
                                          single ? 1 : 0, p->cur_nzh, cmom};

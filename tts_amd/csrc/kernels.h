@@ -53,6 +53,20 @@ constexpr int kWavesPerBlock = GLV_WAVES_PER_BLOCK;
 #define GLV_DEPOSIT 1
 #endif
 
+// LDS of a workgroup, in cf units: the table region - for n_fft 1024 long enough to hold, behind
+// the pass twiddles (which some kernels keep reading), the deposits of kWavesPerBlock - 1 runs -
+// then one exchange buffer per wave, then (n_fft 1024) the shared boundary blocks.
+template <int A>
+constexpr int deposit_offset() {
+    return Geo<A>::TW_A + Geo<A>::TW_B;
+}
+template <int A, int HB>
+constexpr int table_span() {
+    using G = Geo<A>;
+    constexpr int need = deposit_offset<A>() + (kWavesPerBlock - 1) * Engine<A, HB>::kShareFloats / 2;
+    return A == 1 && need > G::TABLES ? need : G::TABLES;
+}
+
 __device__ __forceinline__ void wave_sync() {
     // Orders this wave's LDS writes before its later LDS reads (other lanes' data).
     // One wave's DS operations execute in issue order, so no counter wait is needed;
@@ -60,6 +74,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- iteration-spanning kernels: waiting for a neighbouring run ----
+// A run's progress word holds the number of iterations whose boundary blocks it has written
+// through to memory.  The poll is a device-scope load (served past this CU's L1), one per
+// wave instruction; between polls the wave sleeps.  The wait is bounded: when it runs out (a
+// workgroup of the launch is not resident, say because another process holds part of the
+// device) the status word is raised, the wave stops waiting for good and finishes its loop on
+// whatever it reads - the call's results are void, and the host sees the status word.
+#ifndef GLV_SPIN_LIMIT
+#define GLV_SPIN_LIMIT (1 << 17)
+#endif
+// 1: the loads an iteration's first frame waits for are issued at the end of the iteration before
+// (under the wait for its stores) instead of after the preload (measured: no difference)
+#ifndef GLV_EARLY_PREFETCH
+#define GLV_EARLY_PREFETCH 0
+#endif
+__device__ __forceinline__ int poll_word(const int* w) {
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns false when the wait ran out (or another wave's did)
+__device__ __forceinline__ bool wait_progress(const int* word, int want, int* status, int* host_status) {
+    for (int spins = 0; spins < GLV_SPIN_LIMIT; ++spins) {
+        if (poll_word(word) >= want) return true;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 255) == 255 && poll_word(status) != 0) return false;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr(status, 1);
+        __hip_atomic_fetch_or(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return false;
 }
 
 // second launch bound = waves per SIMD the register allocator must leave room for
@@ -74,7 +120,7 @@ __device__ __forceinline__ void wave_sync() {
 // 19: the shader clock at its start and end)
 __device__ unsigned long long glv_wave_times[20 * 16384];
 #define GLV_STAMP(k)                                                                          \
-    if ((MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ITER1) && (threadIdx.x & 63) == 0) {           \
+    if (stamp_on && (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_ITER1 || MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P) && (threadIdx.x & 63) == 0) {           \
         const int w_ = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);                      \
         if (w_ < 16384 && (k) < 18) glv_wave_times[20 * w_ + (k)] = wall_clock64();                        \
         if (w_ < 16384 && ((k) == 0 || (k) == 3)) glv_wave_times[20 * w_ + 18 + ((k) == 3)] = clock64(); \
@@ -84,20 +130,56 @@ __device__ unsigned long long glv_wave_times[20 * 16384];
 #endif
 
 template <int A, int HB, int MODE, bool SC>
+__device__ __forceinline__ void gl_engine_body(IterArgs a);
+
+template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
+    gl_engine_body<A, HB, MODE, SC>(a);
+}
+
+// The iteration-spanning kernels (n_fft 1024) must fit three workgroups per compute unit, or a
+// device-filling call is not resident as a whole: their register budget is stated outright.
+#ifndef GLV_PERSIST_VGPRS
+#define GLV_PERSIST_VGPRS 168
+#endif
+template <int HB, int MODE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, GLV_MIN_WAVES_A1) __attribute__((amdgpu_num_vgpr(GLV_PERSIST_VGPRS))) void
+gl_persist_kernel(IterArgs a) {
+    gl_engine_body<1, HB, MODE, false>(a);
+}
+
+template <int A, int HB, int MODE, bool SC>
+__device__ __forceinline__ void gl_engine_body(IterArgs a) {
     using G = Geo<A>;
     // Kernels that can complete run boundaries on the producer's side.  They keep every table in
     // registers (the default iteration kernels have the room anyway), so that after the set-up
     // the table region of LDS is free to hold the deposits.
+    // all iterations of the call in this launch (the frame loop below runs once per iteration)
+    constexpr bool kPersist = MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P;
     constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN ||
-                          MODE == MODE_TRAFFIC_LIN_Z;
+                          MODE == MODE_TRAFFIC_LIN_Z || kPersist;
     constexpr bool kCanDeposit = (kLin || MODE == MODE_ISTFT) && !SC && A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
-    using Eng = Engine<A, HB, (kLin && !SC) || kCanDeposit>;
-    static_assert(!kCanDeposit || (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= G::TABLES,
+    // (the iteration-spanning kernels read the second pass's twiddles from LDS: with them in
+    // registers as well they do not fit three workgroups to a compute unit)
+    using Eng = Engine<A, HB, kPersist ? 2 : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist>;
+    constexpr int kSpan = table_span<A, HB>();
+    static_assert(!kCanDeposit || deposit_offset<A>() + (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= kSpan,
                   "the deposits of a workgroup must fit the table region");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tables = reinterpret_cast<cf*>(smem);
+    if (kPersist) {
+        // what these kernels are never launched with, made known to the compiler
+        a.raw_in = 0;
+        a.t_origin = 0;
+        a.draw = 0;
+        a.sc_partial = nullptr;
+    }
+#ifdef GLV_WAVE_TIMES
+    // iteration-spanning kernels stamp their middle iteration: 0 its start, 1 neighbours waited
+    // for, 2 preload issued, 4.. the frames, 3 its end
+    bool stamp_on = !(MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P);
+#endif
     GLV_STAMP(0)
     {
         // stage the tables: all of a thread's loads are issued before the first is stored, so
@@ -129,16 +211,38 @@ gl_engine_kernel(IterArgs a) {
     // kernels whose waves hand boundary blocks to each other through LDS meet at a barrier after
     // the preload: there a wave without a run has to stay until then
     constexpr bool kShare = kLin && !SC && A == 1 && GLV_SHARE_BOUNDARY;
+    // iteration-spanning kernels whose waves exchange blocks through LDS or through this CU's own
+    // stores: one more barrier separates an iteration's last stores from the next one's first loads
+    constexpr bool kEndBarrier = kPersist && (kShare || kCanDeposit);
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
-    if (!live) {
-        // a wave without a run only keeps the workgroup's barriers company
-        if (kShare || deposit) __syncthreads();  // after the set-up
-        if (deposit) __syncthreads();            // before the tails are completed
+    const int n_outer = kPersist ? a.n_iter : 1;
+    if (kPersist && a.census) {
+        // how many workgroups of this launch are resident together: every workgroup arrives once
+        // and waits (bounded) until all have; progress[0] counts arrivals, progress[1] the
+        // workgroups that saw every other one arrive
+        if (threadIdx.x == 0) {
+            atomicAdd(a.progress, 1);
+            bool all = false;
+            for (int spins = 0; spins < (1 << 14) && !all; ++spins) {
+                all = poll_word(a.progress) >= (int)gridDim.x;
+                if (!all) __builtin_amdgcn_s_sleep(16);
+            }
+            if (all) atomicAdd(a.progress + 1, 1);
+        }
         return;
     }
-    cf* xb = tables + G::TABLES + wave * G::XBUF;
-    cf* shared_blocks = tables + G::TABLES + kWavesPerBlock * G::XBUF;  // [wave][kShareFloats / 2]
+    if (!live) {
+        // a wave without a run only keeps the workgroup's barriers company
+        for (int k = 0; k < n_outer; ++k) {
+            if (kShare || (deposit && k == 0)) __syncthreads();  // after the set-up
+            if (deposit) __syncthreads();                        // before the tails are completed
+            if (kEndBarrier) __syncthreads();
+        }
+        return;
+    }
+    cf* xb = tables + kSpan + wave * G::XBUF;
+    cf* shared_blocks = tables + kSpan + kWavesPerBlock * G::XBUF;  // [wave][kShareFloats / 2]
 
     RunDesc rd = a.runs[live ? ri : 0];
     rd.utt = __builtin_amdgcn_readfirstlane(rd.utt);
@@ -149,7 +253,8 @@ gl_engine_kernel(IterArgs a) {
     e.init(a, tables, lane, rd);
     if (kCanDeposit && deposit) {
         // wave w > 0 deposits for wave w - 1 when its run continues that wave's utterance
-        cf* area = tables;  // [wave - 1][kShareFloats / 2], over the tables once every wave has read them
+        // [wave - 1][kShareFloats / 2], over the tables that every wave by then holds in registers
+        cf* area = tables + deposit_offset<A>();
         if (wave > 0 && __builtin_amdgcn_readfirstlane(a.runs[ri - 1].utt) == rd.utt)
             e.deposit_out = area + (wave - 1) * (Eng::kShareFloats / 2);
         if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs &&
@@ -157,8 +262,69 @@ gl_engine_kernel(IterArgs a) {
             e.deposit_in = area + wave * (Eng::kShareFloats / 2);
     }
     if (!kShare && deposit) __syncthreads();  // every wave has taken its tables out of LDS
+    // Iteration-spanning kernels: a boundary with the previous / next run of the utterance that
+    // is not completed through LDS goes through memory, i.e. this run reads what that run wrote
+    // in the previous iteration of the SAME launch (and the other way round).  Such blocks are
+    // written through (Engine::heads_shared / tails_shared), the writer raises its progress word
+    // once they have left, and the reader waits for that word before an iteration's first load,
+    // then drops this CU's cached copies of anything older.
+    bool wait_prev = false, wait_next = false;
+    if (kPersist) {
+        wait_prev = rd.t_begin > 0 && e.deposit_out == nullptr;
+        wait_next = rd.t_end < rd.n_frames && e.deposit_in == nullptr;
+        e.heads_shared = wait_prev;
+        e.tails_shared = wait_next;
+    }
+    bool waiting = true;  // false once a wait has run out
+    int g_cur = 0;        // generation the coming iteration reads
     constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
     constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1;
+    // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
+    constexpr int kNzh =
+        (MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN_Z || MODE == MODE_ITER_LIN_Z_P) ? Eng::NP / 2 : Eng::NP;
+    // iteration-spanning kernels: the buffers of iteration k, and the loads its first frame waits
+    // for (they touch nothing a neighbour writes, so they are issued as early as possible: for
+    // k > 0 at the end of iteration k - 1, under the wait for its stores)
+    auto enter_iteration = [&](int k) {
+        const int g_out = g_cur == 2 ? 0 : g_cur + 1, g_prev = k == 0 ? g_cur : (g_cur == 0 ? 2 : g_cur - 1);
+        auto pick = [](float* const (&g)[3], int i) { return i == 0 ? g[0] : (i == 1 ? g[1] : g[2]); };
+        a.y_in = pick(a.gen_main, g_cur);
+        a.y_in_tail = pick(a.gen_tail, g_cur);
+        a.y_prev = pick(a.gen_main, g_prev);
+        a.y_prev_tail = pick(a.gen_tail, g_prev);
+        a.y_out = pick(a.gen_main, g_out);
+        a.y_out_tail = pick(a.gen_tail, g_out);
+        a.has_prev = k > 0;
+        g_cur = g_out;
+#if GLV_EARLY_PREFETCH
+        e.prefetch_block_pair(a, e.run.t_begin);
+        e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
+#endif
+    };
+    if constexpr (kPersist) {
+        // the blocks after the run's last frame always come from LDS: the next run's published
+        // preload, or this run's own (preload_next); slot wave + 1 either way
+        e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
+        enter_iteration(0);
+    }
+    for (int k = 0; k < n_outer; ++k) {
+#ifdef GLV_WAVE_TIMES
+    if (kPersist) stamp_on = k == a.n_iter / 2;
+    if (kPersist) { GLV_STAMP(0) }
+#endif
+    if (kPersist) {
+        if (k > 0) {
+            e.begin_iteration();
+            if (wait_prev || wait_next) {
+                if (waiting && wait_prev) waiting = wait_progress(a.progress + (int64_t)(ri - 1) * kProgressStride, k, a.status, a.host_status);
+                if (waiting && wait_next) waiting = wait_progress(a.progress + (int64_t)(ri + 1) * kProgressStride, k, a.status, a.host_status);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+#ifdef GLV_WAVE_TIMES
+        GLV_STAMP(1)
+#endif
+    }
     if (kSingle) {
         // one frame per wave: the run is the frame
         const int t = e.run.t_begin;
@@ -192,8 +358,6 @@ gl_engine_kernel(IterArgs a) {
         e.ph6_single(a, t, xb);
         GLV_STAMP(3)
     }
-    // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
-    constexpr int kNzh = (MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN_Z) ? Eng::NP / 2 : Eng::NP;
     if (!kSingle && !kLin && MODE != MODE_ISTFT) {
         e.preload(a);
         e.prefetch_block(a, e.run.t_begin);
@@ -204,18 +368,38 @@ gl_engine_kernel(IterArgs a) {
     }
     if constexpr (kShare) {
         cf* mine = shared_blocks + wave * (Eng::kShareFloats / 2);
-        if (live) {
+        if constexpr (kPersist) {
+            // a run whose successor is not an LDS neighbour makes the blocks after its last frame
+            // itself (into the slot that neighbour would have published to), and only a run with
+            // an LDS predecessor publishes: one writer per slot
+            if (e.deposit_in == nullptr) {
+                const cf* keep = e.share_next;
+                e.share_next = nullptr;
+                e.preload_next(a, mine + Eng::kShareFloats / 2);
+                e.share_next = keep;
+            }
+            GLV_SCHED_FENCE();
+            e.template preload_lin<SC>(a);
+            if (e.deposit_out != nullptr) e.publish_preload(mine);
+            GLV_SCHED_FENCE();
+        } else if (live) {
             e.template preload_lin<SC>(a);
             e.publish_preload(mine);
         }
         __syncthreads();
         // the next run, if it continues this utterance inside this workgroup
-        if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
+        if (!kPersist && wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
             const int next_utt = __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt);
             if (next_utt == e.run.utt) e.share_next = mine + Eng::kShareFloats / 2;
         }
     }
-    if (kLin) {
+#if !GLV_EARLY_PREFETCH
+    if (kPersist) {
+        e.prefetch_block_pair(a, e.run.t_begin);
+        e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
+    }
+#endif
+    if (kLin && !kPersist) {
         if (!kShare) e.template preload_lin<SC>(a);
         e.prefetch_block(a, e.run.t_begin);
         e.prefetch_block_prev(a, e.run.t_begin);
@@ -224,18 +408,17 @@ gl_engine_kernel(IterArgs a) {
     if (MODE == MODE_ITER || MODE == MODE_TRAFFIC) e.prefetch_spec(a, e.run.t_begin);
     if (kRc) e.prefetch_s(a, e.run.t_begin);
     GLV_STAMP(2)
-#if GLV_PRIO == 1
+    constexpr bool kPrio = GLV_PRIO == 1;
     const int prio_n = e.run.t_end - e.run.t_begin;
     const int prio_q1 = e.run.t_begin + (prio_n + 1) / 2, prio_q2 = e.run.t_end - 1 - (prio_n + 7) / 8,
               prio_q3 = e.run.t_end - 1;
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    if (kPrio) __builtin_amdgcn_s_setprio(3);
     for (int t = e.run.t_begin; !kSingle && t < e.run.t_end; ++t) {
-#if GLV_PRIO == 1
-        if (t == prio_q1) __builtin_amdgcn_s_setprio(2);
-        else if (t == prio_q2) __builtin_amdgcn_s_setprio(1);
-        else if (t == prio_q3) __builtin_amdgcn_s_setprio(0);
-#endif
+        if (kPrio) {
+            if (t == prio_q1) __builtin_amdgcn_s_setprio(2);
+            else if (t == prio_q2) __builtin_amdgcn_s_setprio(1);
+            else if (t == prio_q3) __builtin_amdgcn_s_setprio(0);
+        }
         GLV_STAMP(4 + t - e.run.t_begin)
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
@@ -335,7 +518,21 @@ gl_engine_kernel(IterArgs a) {
     }
     if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
-    GLV_STAMP(3)
+    if constexpr (kPersist) {
+        if (k + 1 < n_outer) enter_iteration(k + 1);
+        // every store of this iteration has left (the blocks other workgroups read went out
+        // written through); only then does the run's progress word rise
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((wait_prev || wait_next) && lane == 0)
+            __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride, k + 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (kEndBarrier) __syncthreads();
+#ifdef GLV_WAVE_TIMES
+        GLV_STAMP(3)
+#endif
+    }
+    }  // iterations of an iteration-spanning kernel (one pass otherwise)
+    if (!kPersist) { GLV_STAMP(3) }
     if (SC) {
         float num = e.sc_num, den = e.sc_den;
 #pragma unroll

@@ -172,6 +172,20 @@ class GriffinLimPlan:
             self._handle, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), int(arr.shape[0]),
             _stream_ptr(self.device)))
 
+    def status(self):
+        """Raises if a wait inside an iteration-spanning launch ran out (glv_plan_status): the
+        results of that call are void.  Ask after synchronising with the stream."""
+        _lib.check(self.lib.glv_plan_status(self._handle))
+
+    def persistent_capacity(self, variant=1):
+        """Workgroups of the iteration-spanning kernel seen resident together at plan creation
+        (variant 0: all bins kept, 1: zero-for-good bins left out)."""
+        return int(self.lib.glv_plan_persistent_capacity(self._handle, int(variant)))
+
+    def last_loop_launches(self):
+        """Kernel launches the iteration loop of the last call took (1: all iterations in one)."""
+        return int(self.lib.glv_plan_last_loop_launches(self._handle))
+
     def last_loop_ms(self):
         ms = ctypes.c_float()
         _lib.check(self.lib.glv_plan_last_loop_ms(self._handle, ctypes.byref(ms)))
@@ -586,7 +600,9 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
         print(len(host) / 22050)  # librosa.get_duration(y=audio) assumes sr=22050
     if return_tensor:
         return audio
-    return audio.cpu().numpy()
+    host = audio.cpu().numpy()
+    plan.status()  # the copy has waited for the stream: a void result is reported, not returned
+    return host
 
 
 def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop_length=256,
@@ -673,7 +689,11 @@ def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_len
         seed, phase0 = 0, _phase_tensor(init_phase, plan.n_bins, frames, plan.device)
     with plan.call_state(None, None):
         y = plan.griffinlim(S, [frames], phase0=phase0, seed=seed, n_iter=n_iter, momentum=momentum)[0]
-    return y if return_tensor else y.cpu().numpy()
+    if return_tensor:
+        return y
+    host = y.cpu().numpy()
+    plan.status()
+    return host
 
 
 def audio_to_mel_db(y, sr=22050, n_fft=2048, hop_length=256, win_length=2048, n_mels=80, fmax=8000, *,
