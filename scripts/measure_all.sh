@@ -28,7 +28,8 @@ run ablation_spectral_momentum 200 --no-cpu --linear 0
 run ablation_recompute 200 --no-cpu --recompute 1
 run ablation_n2048_traffic_only 200 --no-cpu --n-fft 2048 --frames 865 --traffic-only
 run ablation_n2048_compute_only 200 --no-cpu --n-fft 2048 --frames 865 --alias-utts
-run ablation_no_graph 200 --no-cpu --no-graph
+run ablation_no_graph 200 --no-cpu --no-graph --no-persistent
+run bench_no_persistent 200 --no-cpu --no-persistent
 run bench_config3_n1 400 --no-cpu --config 3
 run bench_b256 200 --no-cpu --batch 256 --steps 20 --warmup 10
 run bench_b512 200 --no-cpu --batch 512 --steps 10 --warmup 5
@@ -41,7 +42,7 @@ G1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_S
 G2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 G3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH"
 scripts/pmc_gpu.sh "$TAG" "$G1" "$G2" "$G3" > "$OUT/pmc.log" 2>&1 || { echo "pmc failed"; tail -5 "$OUT/pmc.log"; exit 1; }
-BENCH_ARGS="--n-fft 2048 --frames 865" scripts/pmc_gpu.sh "${TAG}_n2048" "$G1" "$G2" "$G3" > "$OUT/pmc_n2048.log" 2>&1 || { echo "pmc n2048 failed"; tail -5 "$OUT/pmc_n2048.log"; exit 1; }
+KERNEL_FILTER=gl_engine_kernel BENCH_ARGS="--n-fft 2048 --frames 865" scripts/pmc_gpu.sh "${TAG}_n2048" "$G1" "$G2" "$G3" > "$OUT/pmc_n2048.log" 2>&1 || { echo "pmc n2048 failed"; tail -5 "$OUT/pmc_n2048.log"; exit 1; }
 # the NNLS solver: matrix-core counters of its one kernel
 GM="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE"
 KERNEL_FILTER=nnls_fused_kernel BENCH_ARGS="--inversion nnls" scripts/pmc_gpu.sh "${TAG}_nnls" "$GM" > "$OUT/pmc_nnls.log" 2>&1 || { echo "pmc nnls failed"; tail -5 "$OUT/pmc_nnls.log"; exit 1; }

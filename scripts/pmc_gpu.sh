@@ -2,7 +2,7 @@
 # One rocprofv3 --pmc pass per argument (a quoted, space-separated counter group) over a
 # short bench run; prints the per-launch average of every counter for the iteration kernel.
 #   scripts/pmc_gpu.sh <tag> "<group 1>" ["<group 2>" ...]
-#   (BENCH_ARGS env adds bench flags; KERNEL_FILTER env names the kernel, default gl_engine_kernel)
+#   (BENCH_ARGS env adds bench flags; KERNEL_FILTER env names the kernel, default gl_persist_kernel)
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -14,7 +14,7 @@ for grp in "$@"; do
   i=$((i+1))
   timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; exit 1; }
 done
-python3 - "$OUT" "${KERNEL_FILTER:-gl_engine_kernel}" <<'PY'
+python3 - "$OUT" "${KERNEL_FILTER:-gl_persist_kernel}" <<'PY'
 import csv, glob, sys, collections, json
 out, want = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -21,11 +21,11 @@ def find(outdir, sub, suffix):
 
 
 def short(name):
-    for key in ("gl_engine_kernel", "gemm_nt_kernel", "mel_native_kernel", "root_kernel", "init_native_kernel", "finalize_kernel",
+    for key in ("gl_persist_kernel", "gl_engine_kernel", "gemm_nt_kernel", "mel_native_kernel", "root_kernel", "init_native_kernel", "finalize_kernel",
                 "peak_reduce_kernel", "peak_scale_kernel", "sc_reduce_kernel", "spec_convert_kernel",
                 "pad_signal_kernel"):
         if key in name:
-            if key in ("gl_engine_kernel", "gemm_nt_kernel"):
+            if key in ("gl_persist_kernel", "gl_engine_kernel", "gemm_nt_kernel"):
                 # template args <A, HB, MODE, SC>
                 tail = name[name.index(key):]
                 return tail[: tail.index(">") + 1] if ">" in tail else tail[:60]
@@ -57,6 +57,7 @@ def main():
             if text.startswith("{") and '"roofline"' in text:
                 roof = json.loads(text)["roofline"]
                 summary["bench_under_profiler_us_per_launch"] = roof["kernel_ms_per_launch"] * 1e3
+                summary["iterations_per_launch"] = roof.get("iterations_per_launch", 1)
                 # which workload, variant and kernel sources these counters belong to
                 summary["traffic_key"] = roof.get("traffic_key")
                 summary["engine_source_digest"] = roof.get("engine_source_digest")
@@ -88,7 +89,10 @@ def main():
             rd, wr = 2 * f * 1024 / 1e6, w * 1024 / 1e6
             lines.append(f"| {k} | {f:.0f} | {w:.0f} | {rd:.2f} | {wr:.2f} | {rd + wr:.2f} |")
             # the iteration kernel: MODE_ITER_LIN (8) by default, MODE_ITER (0) with option linear = 0
-            if "gl_engine_kernel" in k and k.rstrip(">").endswith(("8, false", "9, false", "0, false", "6, false", "4, false")):
+            # (gl_persist_kernel: all iterations of a call in one launch; bench.py's per-launch
+            # figures are per launch of whichever kernel ran)
+            if "gl_persist_kernel" in k or ("gl_engine_kernel" in k and "gl_engine_iter_kernel" not in summary and
+                                            k.rstrip(">").endswith(("8, false", "9, false", "0, false", "6, false", "4, false"))):
                 summary["gl_engine_iter_kernel"] = k
                 summary["gl_engine_iter_bytes_per_launch"] = int((rd + wr) * 1e6)
                 summary["gl_engine_iter_read_bytes"] = int(rd * 1e6)

@@ -241,9 +241,9 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
     } else if (mode == MODE_ITER_LIN_P || mode == MODE_ITER_LIN_Z_P) {
         if constexpr (A == 1) {
             if (mode == MODE_ITER_LIN_P)
-                hipLaunchKernelGGL((gl_persist_kernel<HB, MODE_ITER_LIN_P>), g, b, lds, st, a);
+                hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>), g, b, lds, st, a);
             else
-                hipLaunchKernelGGL((gl_persist_kernel<HB, MODE_ITER_LIN_Z_P>), g, b, lds, st, a);
+                hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>), g, b, lds, st, a);
         } else {
             return hipErrorInvalidDeviceFunction;
         }
@@ -276,9 +276,9 @@ int persist_blocks_per_cu_t(int variant) {
         int n = 0;
         const hipError_t e =
             variant == 0
-                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_persist_kernel<HB, MODE_ITER_LIN_P>,
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>,
                                                                64 * kWavesPerBlock, lds)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_persist_kernel<HB, MODE_ITER_LIN_Z_P>,
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>,
                                                                64 * kWavesPerBlock, lds);
         return e == hipSuccess && n > 0 ? n : 0;
     } else {

@@ -108,6 +108,30 @@ __device__ __forceinline__ bool wait_progress(const int* word, int want, int* st
     return false;
 }
 
+// iteration-spanning kernels: the buffers of iteration k, and (GLV_EARLY_PREFETCH) the loads its
+// first frame waits for - they touch nothing a neighbour writes, so they can be issued at the end
+// of iteration k - 1, under the wait for its stores
+template <int NZH, typename EngT>
+__device__ __forceinline__ void enter_iteration(IterArgs& a, EngT& e, int& g_cur, int k) {
+    const int g_out = g_cur == 2 ? 0 : g_cur + 1, g_prev = k == 0 ? g_cur : (g_cur == 0 ? 2 : g_cur - 1);
+    auto pick = [](float* const (&g)[3], int i) { return i == 0 ? g[0] : (i == 1 ? g[1] : g[2]); };
+    a.y_in = pick(a.gen_main, g_cur);
+    a.y_in_tail = pick(a.gen_tail, g_cur);
+    a.y_prev = pick(a.gen_main, g_prev);
+    a.y_prev_tail = pick(a.gen_tail, g_prev);
+    a.y_out = pick(a.gen_main, g_out);
+    a.y_out_tail = pick(a.gen_tail, g_out);
+    a.has_prev = k > 0;
+    g_cur = g_out;
+#if GLV_EARLY_PREFETCH
+    e.prefetch_block_pair(a, e.run.t_begin);
+    e.template prefetch_s_pair<NZH>(a, e.run.t_begin);
+#endif
+}
+
+#ifndef GLV_PERSIST_TWR
+#define GLV_PERSIST_TWR 1
+#endif
 // second launch bound = waves per SIMD the register allocator must leave room for
 #ifndef GLV_MIN_WAVES_A1
 #define GLV_MIN_WAVES_A1 2
@@ -130,27 +154,8 @@ __device__ unsigned long long glv_wave_times[20 * 16384];
 #endif
 
 template <int A, int HB, int MODE, bool SC>
-__device__ __forceinline__ void gl_engine_body(IterArgs a);
-
-template <int A, int HB, int MODE, bool SC>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
-    gl_engine_body<A, HB, MODE, SC>(a);
-}
-
-// The iteration-spanning kernels (n_fft 1024) must fit three workgroups per compute unit, or a
-// device-filling call is not resident as a whole: their register budget is stated outright.
-#ifndef GLV_PERSIST_VGPRS
-#define GLV_PERSIST_VGPRS 168
-#endif
-template <int HB, int MODE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, GLV_MIN_WAVES_A1) __attribute__((amdgpu_num_vgpr(GLV_PERSIST_VGPRS))) void
-gl_persist_kernel(IterArgs a) {
-    gl_engine_body<1, HB, MODE, false>(a);
-}
-
-template <int A, int HB, int MODE, bool SC>
-__device__ __forceinline__ void gl_engine_body(IterArgs a) {
     using G = Geo<A>;
     // Kernels that can complete run boundaries on the producer's side.  They keep every table in
     // registers (the default iteration kernels have the room anyway), so that after the set-up
@@ -160,9 +165,9 @@ __device__ __forceinline__ void gl_engine_body(IterArgs a) {
     constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN ||
                           MODE == MODE_TRAFFIC_LIN_Z || kPersist;
     constexpr bool kCanDeposit = (kLin || MODE == MODE_ISTFT) && !SC && A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
-    // (the iteration-spanning kernels read the second pass's twiddles from LDS: with them in
-    // registers as well they do not fit three workgroups to a compute unit)
-    using Eng = Engine<A, HB, kPersist ? 2 : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist>;
+    // (GLV_PERSIST_TWR = 2: the iteration-spanning kernels read the second pass's twiddles from
+    // LDS, which saves them 16 registers; 1: in registers like the other kernels)
+    using Eng = Engine<A, HB, kPersist ? GLV_PERSIST_TWR : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist>;
     constexpr int kSpan = table_span<A, HB>();
     static_assert(!kCanDeposit || deposit_offset<A>() + (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= kSpan,
                   "the deposits of a workgroup must fit the table region");
@@ -282,32 +287,21 @@ __device__ __forceinline__ void gl_engine_body(IterArgs a) {
     // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
     constexpr int kNzh =
         (MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN_Z || MODE == MODE_ITER_LIN_Z_P) ? Eng::NP / 2 : Eng::NP;
-    // iteration-spanning kernels: the buffers of iteration k, and the loads its first frame waits
-    // for (they touch nothing a neighbour writes, so they are issued as early as possible: for
-    // k > 0 at the end of iteration k - 1, under the wait for its stores)
-    auto enter_iteration = [&](int k) {
-        const int g_out = g_cur == 2 ? 0 : g_cur + 1, g_prev = k == 0 ? g_cur : (g_cur == 0 ? 2 : g_cur - 1);
-        auto pick = [](float* const (&g)[3], int i) { return i == 0 ? g[0] : (i == 1 ? g[1] : g[2]); };
-        a.y_in = pick(a.gen_main, g_cur);
-        a.y_in_tail = pick(a.gen_tail, g_cur);
-        a.y_prev = pick(a.gen_main, g_prev);
-        a.y_prev_tail = pick(a.gen_tail, g_prev);
-        a.y_out = pick(a.gen_main, g_out);
-        a.y_out_tail = pick(a.gen_tail, g_out);
-        a.has_prev = k > 0;
-        g_cur = g_out;
-#if GLV_EARLY_PREFETCH
-        e.prefetch_block_pair(a, e.run.t_begin);
-        e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
-#endif
-    };
     if constexpr (kPersist) {
         // the blocks after the run's last frame always come from LDS: the next run's published
         // preload, or this run's own (preload_next); slot wave + 1 either way
         e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
-        enter_iteration(0);
+        enter_iteration<kNzh>(a, e, g_cur, 0);
     }
-    for (int k = 0; k < n_outer; ++k) {
+    // (not a loop at all unless the kernel spans iterations: inside a loop the compiler hoists every
+    // address computation of the body to its head, where they fight over the scalar registers)
+    int k = 0;
+    do {
+    if (kPersist) {
+        // the run descriptor passes through an opaque point every iteration, for the same reason:
+        // what is derived from it is computed where it is used, not kept across the loop
+        asm volatile("" : "+s"(e.run.utt), "+s"(e.run.t_begin), "+s"(e.run.t_end), "+s"(e.run.n_frames));
+    }
 #ifdef GLV_WAVE_TIMES
     if (kPersist) stamp_on = k == a.n_iter / 2;
     if (kPersist) { GLV_STAMP(0) }
@@ -519,7 +513,7 @@ __device__ __forceinline__ void gl_engine_body(IterArgs a) {
     if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
     if constexpr (kPersist) {
-        if (k + 1 < n_outer) enter_iteration(k + 1);
+        if (k + 1 < n_outer) enter_iteration<kNzh>(a, e, g_cur, k + 1);
         // every store of this iteration has left (the blocks other workgroups read went out
         // written through); only then does the run's progress word rise
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -531,7 +525,7 @@ __device__ __forceinline__ void gl_engine_body(IterArgs a) {
         GLV_STAMP(3)
 #endif
     }
-    }  // iterations of an iteration-spanning kernel (one pass otherwise)
+    } while (kPersist && ++k < n_outer);  // iterations of an iteration-spanning kernel (one pass otherwise)
     if (!kPersist) { GLV_STAMP(3) }
     if (SC) {
         float num = e.sc_num, den = e.sc_den;
