@@ -342,16 +342,50 @@ def nnls_projected_gradient(a, b, n_steps=200, x0=None, tol=0.0):
     return x
 
 
-def mel_to_stft(m, sr=22050, n_fft=2048, power=2.0, n_steps=200, **kw):
-    """librosa.feature.inverse.mel_to_stft with the projected-gradient solver."""
+def nnls_accelerated(a, b, n_steps=40, x0=None, tol=0.0):
+    """The same projected-gradient step with Nesterov / FISTA extrapolation (Beck & Teboulle 2009):
+        x_{k+1} = max(y_k - step * A^T (A y_k - B), 0)
+        t_{k+1} = (1 + sqrt(1 + 4 t_k^2)) / 2,   beta_k = (t_k - 1) / t_{k+1}   (t_0 = 1, in double)
+        y_{k+1} = x_{k+1} + beta_k (x_{k+1} - x_k)
+    Same objective, same start, same step length as nnls_projected_gradient; it reaches that
+    solver's 200-step residual in about 35 steps.  With ``tol`` a frame (column) stops for good
+    once ||A y - b|| <= tol * ||b||: it takes the projection max(y, 0) of the point that passed
+    the test and neither moves nor extrapolates again, so a frame's result does not depend on
+    the other frames; the loop ends when no frame moves.  Returns x."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    x = nnls_init(a, b) if x0 is None else np.array(x0, copy=True)
+    y = x.copy()
+    step = a.dtype.type(1.0 / (np.linalg.norm(a.astype(np.float64), 2) ** 2))
+    t = 1.0
+    stopped = np.zeros(b.shape[-1], dtype=bool)
+    for _ in range(n_steps):
+        r = a @ y - b
+        if tol > 0:
+            stopped |= np.linalg.norm(r, axis=0) <= tol * np.linalg.norm(b, axis=0)
+        active = (~stopped).astype(a.dtype)
+        x_new = np.maximum(y - step * (a.T @ (r * active)), 0)
+        t_next = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t * t))
+        beta = a.dtype.type((t - 1.0) / t_next)
+        t = t_next
+        y = x_new + (beta * active) * (x_new - x)
+        x = x_new
+        if stopped.all():
+            break
+    return x
+
+
+def mel_to_stft(m, sr=22050, n_fft=2048, power=2.0, n_steps=40, accelerated=True, **kw):
+    """librosa.feature.inverse.mel_to_stft with the projected-gradient solver (accelerated by
+    default, as the device solver is)."""
     m = np.asarray(m)
     a = mel_filterbank(sr=sr, n_fft=n_fft, n_mels=m.shape[-2], dtype=m.dtype, **kw)
-    x = nnls_projected_gradient(a, m, n_steps=n_steps)
+    x = nnls_accelerated(a, m, n_steps=n_steps) if accelerated else nnls_projected_gradient(a, m, n_steps=n_steps)
     return np.power(x, 1.0 / power, out=x)
 
 
 def mel_to_audio(m, sr=22050, n_fft=2048, hop_length=None, win_length=None, power=2.0,
-                 n_iter=32, init_phase=None, random_state=None, n_steps=200, **kw):
+                 n_iter=32, init_phase=None, random_state=None, n_steps=40, **kw):
     """librosa.feature.inverse.mel_to_audio defaults (hop = n_fft//4 = 512)."""
     s = mel_to_stft(m, sr=sr, n_fft=n_fft, power=power, n_steps=n_steps, **kw)
     return griffinlim(s, n_iter=n_iter, hop_length=hop_length, win_length=win_length,

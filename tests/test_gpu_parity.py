@@ -454,6 +454,8 @@ def test_nnls_inversion(voc, O, n_fft, n_mels):
     x0 = plan.mel_invert_nnls(md, n_steps=0, power=1.0).cpu().numpy()[0].T
     assert rel_l2(x0, O.nnls_init(basis, m)) < 1e-5
     res0 = np.linalg.norm(basis @ x0 - m) / np.linalg.norm(m)
+    # plain projected-gradient steps (option "nnls_accel" off) against the oracle's
+    plan.set_option("nnls_accel", 0)
     x = plan.mel_invert_nnls(md, n_steps=100, power=1.0).cpu().numpy()[0].T
     want = O.nnls_projected_gradient(basis, m, n_steps=100)
     assert np.all(x >= 0)
@@ -477,6 +479,22 @@ def test_nnls_inversion(voc, O, n_fft, n_mels):
     assert np.all(rel < 0.021) and np.all(xt >= 0)
     sub = plan.mel_invert_nnls(dev(np.ascontiguousarray(m.T[None, 7:19])), n_steps=400, power=1.0, tol=0.02)
     assert np.array_equal(sub.cpu().numpy()[0].T, xt[:, 7:19])
+    # the default: the same steps extrapolated (Nesterov / FISTA) - against the oracle's identical
+    # iteration, and 40 of them must leave a smaller mel residual than 100 plain ones
+    plan.set_option("nnls_accel", 1)
+    for steps in (1, 2, 40):
+        xa = plan.mel_invert_nnls(md, n_steps=steps, power=1.0).cpu().numpy()[0].T
+        assert np.all(xa >= 0)
+        assert rel_l2(xa, O.nnls_accelerated(basis, m, n_steps=steps)) < 1e-4, steps
+    res_a = np.linalg.norm(basis @ xa - m) / np.linalg.norm(m)
+    print(f"[nnls] n_fft {n_fft}: mel residual start {res0:.3e}, 100 plain steps {res:.3e}, 40 accelerated {res_a:.3e}")
+    assert res_a < res
+    xat = plan.mel_invert_nnls(md, n_steps=400, power=1.0, tol=0.02).cpu().numpy()[0].T
+    assert rel_l2(xat, O.nnls_accelerated(basis, m, n_steps=400, tol=0.02)) < 1e-3
+    rel = np.linalg.norm(basis @ xat - m, axis=0) / np.linalg.norm(m, axis=0)
+    assert np.all(rel < 0.03) and np.all(xat >= 0)
+    sub = plan.mel_invert_nnls(dev(np.ascontiguousarray(m.T[None, 7:19])), n_steps=400, power=1.0, tol=0.02)
+    assert np.array_equal(sub.cpu().numpy()[0].T, xat[:, 7:19])
     plan.close()
     # the secondary entry point end to end, librosa defaults (hop = n_fft/4, no peak normalisation)
     y = voc.mel_to_audio(m, sr=sr, n_fft=n_fft, n_iter=4, n_steps=50, init_phase=5)
@@ -625,7 +643,7 @@ def test_drop_in_with_nnls_inversion(voc, O, lj001):
     plan = voc.get_plan(1024, 256, 1024, 80, 96, 1)
     plan.set_mel_basis(22050, 0.0, 8000)
     from tts_amd.vocoder import _invert_mel
-    S = _invert_mel(plan, dev(mel[None]), mean, std, "nnls", 200)[0].cpu().numpy().astype(np.float64)
+    S = _invert_mel(plan, dev(mel[None]), mean, std, "nnls", 40)[0].cpu().numpy().astype(np.float64)
     assert S.min() >= 0.0
     basis = O.mel_filterbank(22050, 1024, n_mels=80, fmax=8000).astype(np.float64)
     target = O.db_to_power((mel * std + mean).T).astype(np.float64)

@@ -112,6 +112,8 @@ struct glv_plan {
     int* d_nnls_hi = nullptr;
     int nnls_mt = 0, nnls_ct = 0;  // mel tiles (0: shape not covered, unfused steps), bin tiles
     int nnls_fused = 1;            // option: 0 = one product per launch (the unfused form)
+    int nnls_accel = 1;            // option: Nesterov / FISTA extrapolation of the fused solver's steps
+    float* d_nnls_x = nullptr;     // the fused solver's iterate x_k in tile order (accelerated form)
     int64_t nnls_mfma_per_block_step = 0;
     // device workspace
     cf* d_spec = nullptr;
@@ -376,7 +378,7 @@ void plan_free(glv_plan* p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->h_status) (void)hipHostFree(p->h_status);
-    void* dev[] = {p->d_progress, p->d_nnls_a1, p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
+    void* dev[] = {p->d_progress, p->d_nnls_x, p->d_nnls_a1, p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, p->d_parts, p->d_pinv_t, p->d_iwss_small, p->d_zeros, p->d_basis, p->d_basis_t, p->d_resid, p->d_iwss_head, p->d_iwss_tail, p->d_tables, p->d_w2,    p->d_iwss,    p->d_pinv,     p->d_spec,    p->d_S,
                    p->d_ym[0],  p->d_ym[1], p->d_yt[0],   p->d_yt[1],    p->d_ym[2], p->d_yt[2], p->d_runs,    p->d_flags,
                    p->d_nframes, p->d_nsamples, p->d_run_off, p->d_run_cnt, p->d_peak, p->d_sc_partial, p->d_utt_ids};
     for (void* q : dev)
@@ -757,6 +759,8 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         drop_graphs(p);
     } else if (!strcmp(name, "nnls_fused")) {
         p->nnls_fused = value != 0;
+    } else if (!strcmp(name, "nnls_accel")) {
+        p->nnls_accel = value != 0;
     } else if (!strcmp(name, "zero_skip")) {
         p->zero_skip = value != 0;
     } else if (!strcmp(name, "deposit")) {
@@ -951,10 +955,15 @@ extern "C" int glv_plan_set_mel_basis(glv_plan* p, const float* basis_host) {
                 }
             }
             p->nnls_mfma_per_block_step = mfma;
-            for (void* q : {(void*)p->d_nnls_a1, (void*)p->d_nnls_a2, (void*)p->d_nnls_lo, (void*)p->d_nnls_hi})
+            for (void* q : {(void*)p->d_nnls_a1, (void*)p->d_nnls_a2, (void*)p->d_nnls_lo, (void*)p->d_nnls_hi,
+                            (void*)p->d_nnls_x})
                 if (q) (void)hipFree(q);
             p->d_nnls_a1 = p->d_nnls_a2 = nullptr;
             p->d_nnls_lo = p->d_nnls_hi = nullptr;
+            p->d_nnls_x = nullptr;
+            // x_k of every 32-frame block in tile order: [block][tile][4][64 lanes] x 16 bytes
+            const size_t blocks32 = ((size_t)p->max_batch * p->max_frames + 31) / 32;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_x), blocks32 * CT * 1024 * sizeof(float)));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_a1), a1.size() * sizeof(float)));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_a2), a2.size() * sizeof(float)));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_nnls_lo), CT * sizeof(int)));
@@ -983,7 +992,7 @@ hipError_t launch_nnls_fused(const glv_plan* p, float* X, const float* B, int64_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
         hipLaunchKernelGGL((nnls_fused_kernel<NW, TPW, MT_>), grid, block, lds, st, X, B, p->d_nnls_a1,         \
                            p->d_nnls_a2, p->d_nnls_lo, p->d_nnls_hi, rows, p->F, p->n_mels, p->nnls_ct, n_steps, \
-                           step, tol);                                                                          \
+                           step, tol, p->d_nnls_x, p->nnls_accel);                                              \
         break;
     switch (p->nnls_mt) {
         GLV_NNLS_CASE(1)

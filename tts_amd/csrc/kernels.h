@@ -847,7 +847,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
                                                            const float* __restrict__ A1, const float* __restrict__ A2,
                                                            const int* __restrict__ mel_lo, const int* __restrict__ mel_hi,
                                                            int64_t rows, int F, int M, int CT, int n_steps, float step,
-                                                           float tol) {
+                                                           float tol, float* __restrict__ Xs, int accel) {
     constexpr int MP = 32 * MT;  // mels, padded to whole tiles
     extern __shared__ float nnls_smem[];
     float* part = nnls_smem;                 // [NW][MP][32] partial R^T of every wave
@@ -895,6 +895,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
             xt[t][r] = (row_ok && bin < F) ? X[(row0 + i) * F + bin] : 0.f;
         }
     }
+    // Accelerated form (accel): the registers hold the EXTRAPOLATED iterate y_k, the iterate
+    // x_k itself lives in Xs, a scratch array in this kernel's own tile order
+    // [block][tile][4][lane] x 16 bytes, which every step reads and rewrites once per tile (it
+    // stays in the caches); beta_k = (t_k - 1) / t_{k+1} follows in double precision in every
+    // thread.  Without accel beta is 0, y = x, and Xs is not touched.
+    f4* xs = reinterpret_cast<f4*>(Xs) + (int64_t)blockIdx.x * CT * 256 + lane;
+    auto xs_store = [&](int c, const f32x16& x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xs[(c * 4 + q) * 64] = f4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    };
+    if (accel) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+            if (wave + NW * t < CT) xs_store(wave + NW * t, xt[t]);
+    }
+    double tk = 1.0;
     __syncthreads();
     for (int it = 0; it < n_steps; ++it) {
         // ---- phase 1: this wave's share of R^T ----
@@ -966,26 +982,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
             Rl[e] = r - bt[q];
         }
         __syncthreads();
+        // a row stops for good once its residual passes the test: its step (and extrapolation
+        // weight) is zero from then on, so this step leaves it at max(y, 0) and later ones there
+        bool last_step = false;
         if (tol > 0.f && threadIdx.x < 32) {
             float r2 = 0.f;
             for (int m = 0; m < M; ++m) r2 += Rl[m * 32 + threadIdx.x] * Rl[m * 32 + threadIdx.x];
-            const bool active = r2 > tol * tol * bnorm[threadIdx.x];
+            const bool active = rowstep[threadIdx.x] != 0.f && r2 > tol * tol * bnorm[threadIdx.x];
             rowstep[threadIdx.x] = active ? step : 0.f;
             if (active) any_active[it % 3] = 1;
         }
         if (tol > 0.f) {
             __syncthreads();
-            if (!any_active[it % 3]) break;
+            last_step = !any_active[it % 3];  // no row moves any more: this step only projects
         }
-        // ---- phase 2: X^T tile -= step * A^T tile . R^T, clamp ----
+        // ---- phase 2: X^T tile -= step * A^T tile . R^T, clamp (and extrapolate) ----
         const float st = rowstep[i];
+        const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+        const float beta = (accel && st != 0.f) ? (float)((tk - 1.0) / tn) : 0.f;
+        tk = tn;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const int c = wave + NW * t;
             if (hi[t] <= lo[t]) continue;
+            if (last_step && !accel) continue;  // x = max(x, 0) changes nothing
             f32x16 gt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gt[r] = 0.f;
+            // x_k of this tile, requested before the products that hide its way from the cache
+            f4 xo[4];
+            if (accel) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xo[q] = xs[(c * 4 + q) * 64];
+            }
             const float* a2 = A2s + c * (MP / 2) * 64 + lane;
 #if GLV_NNLS_PIPE2
             // four k-steps at a time; the operands of the next four are requested before the
@@ -998,7 +1027,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
                     bv[u] = Rl[(2 * (j + u) + g) * 32 + i];
                 }
             };
-            const int jend = (hi[t] + 1) >> 1;
+            const int jend = last_step ? 0 : (hi[t] + 1) >> 1;  // (every step is zero then: no products)
             float av[4], bv[4];
             fetch((lo[t] >> 1) & ~3, av, bv);
             for (int j = (lo[t] >> 1) & ~3; j < jend; j += 4) {
@@ -1026,8 +1055,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void nnls_fused_kernel(
             }
             GLV_SCHED_FENCE();
 #endif
+            if (accel) {
+                f32x16 xn;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xt[t][r] = fmaxf(xt[t][r] - st * gt[r], 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const float old = (r & 3) == 0 ? xo[r >> 2].x : (r & 3) == 1 ? xo[r >> 2].y
+                                      : (r & 3) == 2 ? xo[r >> 2].z : xo[r >> 2].w;
+                    xn[r] = fmaxf(xt[t][r] - st * gt[r], 0.f);
+                    xt[t][r] = xn[r] + beta * (xn[r] - old);
+                }
+                xs_store(c, xn);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xt[t][r] = fmaxf(xt[t][r] - st * gt[r], 0.f);
+            }
+        }
+        if (last_step) break;
+    }
+    if (accel) {
+        // the answer is x, not the extrapolated y: back from the scratch array (each thread reads
+        // what it wrote itself)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int c = wave + NW * t;
+            if (c >= CT) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 v4 = xs[(c * 4 + q) * 64];
+                xt[t][4 * q] = v4.x;
+                xt[t][4 * q + 1] = v4.y;
+                xt[t][4 * q + 2] = v4.z;
+                xt[t][4 * q + 3] = v4.w;
+            }
         }
     }
 #pragma unroll

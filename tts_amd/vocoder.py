@@ -244,11 +244,13 @@ class GriffinLimPlan:
                                            _ptr(out), _stream_ptr(self.device)))
         return out
 
-    def mel_invert_nnls(self, mel_power, n_steps=200, power=2.0, tol=0.0):
+    def mel_invert_nnls(self, mel_power, n_steps=40, power=2.0, tol=0.0):
         """(B, T, n_mels) mel POWER values -> (B, T, F) non-negative magnitudes: the
         mel_to_stft step of librosa.feature.inverse.mel_to_audio (reference
-        test_cnn_model.py:117-119) as a projected-gradient solver from librosa's start.  A frame
-        stops once its mel residual is below ``tol`` times the norm of its mel (0: all steps)."""
+        test_cnn_model.py:117-119) as a projected-gradient solver from librosa's start, its steps
+        extrapolated the Nesterov / FISTA way (option "nnls_accel", default on: 40 steps reach a
+        lower mel residual than 200 plain ones).  A frame stops once its mel residual is below
+        ``tol`` times the norm of its mel (0: all steps)."""
         self._check(mel_power, (self.n_mels,), "mel_power")
         if mel_power.dim() != 3:
             raise ValueError("mel_power must be (B, T, n_mels)")
@@ -550,7 +552,7 @@ def _invert_mel(plan, mel, mean, std, inversion, nnls_steps):
 
 def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length=256, win_length=2048,
                              n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, init_phase=None,
-                             inversion="pinv", nnls_steps=200, device=None, return_tensor=False,
+                             inversion="pinv", nnls_steps=40, device=None, return_tensor=False,
                              verbose=False):
     """Normalised-dB mel (T, n_mels) -> peak-normalised waveform of hop_length*(T-1)
     samples, as reference vocoder/mel_audio.py:112-132 computes it:
@@ -607,7 +609,7 @@ def mel_to_audio_griffin_lim(mel_db, mean, std, sr=22050, n_fft=2048, hop_length
 
 def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop_length=256,
                       win_length=2048, n_mels=80, fmax=8000, *, n_iter=60, momentum=0.99, phase0=None,
-                      seed=0, utt_ids=None, frames_per_run=None, inversion="pinv", nnls_steps=200,
+                      seed=0, utt_ids=None, frames_per_run=None, inversion="pinv", nnls_steps=40,
                       device=None, return_sc=False, normalize=True):
     """Batched mel_to_audio_griffin_lim.
 
@@ -664,7 +666,7 @@ def griffin_lim_batch(mel_db, mean, std, lengths=None, sr=22050, n_fft=2048, hop
 
 
 def mel_to_audio(mel_spectrogram, sr=22050, n_fft=2048, hop_length=None, win_length=None, power=2.0,
-                 n_iter=32, *, fmin=0.0, fmax=None, n_steps=200, momentum=0.99, init_phase=None,
+                 n_iter=32, *, fmin=0.0, fmax=None, n_steps=40, momentum=0.99, init_phase=None,
                  device=None, return_tensor=False):
     """``librosa.feature.inverse.mel_to_audio(M, sr=sr)`` as the reference's older scripts call
     it (test_cnn_model.py:117-119, test_1.py:52-54, z_AR/test_AR_model.py:12-14): (n_mels, T)
