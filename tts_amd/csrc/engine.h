@@ -162,6 +162,9 @@ struct IterArgs {
 };
 // distance between two runs' progress words: a word is stored by one wave and polled by at most two
 constexpr int kProgressStride = 32;
+// offset of a run's second progress word: iterations whose first R-1 blocks (the half sums its
+// predecessor reads) have been written through
+constexpr int kProgressHeads = 16;
 
 // Loads and stores of the iteration state.  Every byte of it is touched once per launch and not
 // again before the whole working set has passed through the caches, so the accesses can be

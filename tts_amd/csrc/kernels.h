@@ -108,6 +108,41 @@ __device__ __forceinline__ bool wait_progress(const int* word, int want, int* st
     return false;
 }
 
+// 1: the waves of a workgroup of an iteration-spanning kernel do not meet at barriers after the
+// first iteration; what one hands to another through LDS (or through this CU's own stores) is
+// announced by a flag word in LDS that the taker waits for where it needs the data.  A run then
+// depends on its PREDECESSOR at the start of an iteration and on its successor only frames
+// later, so the runs of an utterance fall into a staircase, each a hand-over behind the one
+// before it.  0 (the default): three barriers per iteration.  Measured on MI355X at 64 x 430
+// frames: same bits, but 35.0 against 33.0 us per iteration - the waves still wait for their
+// predecessors every iteration (the time a wave needs for its frames varies with what its SIMD's
+// other waves do, and a chain runs at the pace of its slowest link either way), and the staircase
+// adds about 100 us to the start and the end of a call.
+#ifndef GLV_PERSIST_FLAGS
+#define GLV_PERSIST_FLAGS 0
+#endif
+// flag words in LDS: iterations whose data wave w has (0) published after its preload,
+// (1) deposited (its first R-1 blocks' head sums), (2) stored and drained at its end
+__device__ __forceinline__ void lds_raise(int* flag, int value, int lane) {
+    asm volatile("" ::: "memory");  // the data this announces was written by earlier instructions
+    if (lane == 0) *reinterpret_cast<volatile int*>(flag) = value;
+}
+__device__ __forceinline__ bool lds_wait(const int* flag, int want, int* status, int* host_status) {
+    for (int spins = 0; spins < (GLV_SPIN_LIMIT << 3); ++spins) {
+        if (*reinterpret_cast<const volatile int*>(flag) >= want) {
+            asm volatile("" ::: "memory");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 4095) == 4095 && poll_word(status) != 0) return false;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr(status, 1);
+        __hip_atomic_fetch_or(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return false;
+}
+
 // iteration-spanning kernels: the buffers of iteration k, and (GLV_EARLY_PREFETCH) the loads its
 // first frame waits for - they touch nothing a neighbour writes, so they can be issued at the end
 // of iteration k - 1, under the wait for its stores
@@ -206,6 +241,13 @@ gl_engine_kernel(IterArgs a) {
             if (i < kVec) dst[i] = tmp[k];
         }
     }
+    // the waves' flag words (iteration-spanning kernels), behind the shared boundary blocks
+    int* lflag = nullptr;
+    if constexpr (kPersist) {
+        lflag = reinterpret_cast<int*>(tables + table_span<A, HB>() + kWavesPerBlock * G::XBUF +
+                                       (kWavesPerBlock + 1) * (Engine<A, HB>::kShareFloats / 2));
+        if (threadIdx.x < 3 * kWavesPerBlock) lflag[threadIdx.x] = 0;
+    }
     __syncthreads();
     GLV_STAMP(1)
 
@@ -218,7 +260,8 @@ gl_engine_kernel(IterArgs a) {
     constexpr bool kShare = kLin && !SC && A == 1 && GLV_SHARE_BOUNDARY;
     // iteration-spanning kernels whose waves exchange blocks through LDS or through this CU's own
     // stores: one more barrier separates an iteration's last stores from the next one's first loads
-    constexpr bool kEndBarrier = kPersist && (kShare || kCanDeposit);
+    constexpr bool kFlags = kPersist && GLV_PERSIST_FLAGS;
+    constexpr bool kEndBarrier = kPersist && (kShare || kCanDeposit) && !kFlags;
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
     const int n_outer = kPersist ? a.n_iter : 1;
@@ -241,6 +284,7 @@ gl_engine_kernel(IterArgs a) {
         // a wave without a run only keeps the workgroup's barriers company
         for (int k = 0; k < n_outer; ++k) {
             if (kShare || (deposit && k == 0)) __syncthreads();  // after the set-up
+            if (kFlags) break;                                   // ... the only barrier there is
             if (deposit) __syncthreads();                        // before the tails are completed
             if (kEndBarrier) __syncthreads();
         }
@@ -309,9 +353,18 @@ gl_engine_kernel(IterArgs a) {
     if (kPersist) {
         if (k > 0) {
             e.begin_iteration();
+            // the run before this one has stored its part of the boundary blocks (iteration k - 1):
+            // a flag word in LDS when it is a wave of this workgroup, else its progress word
+            if (kFlags && e.deposit_out != nullptr && waiting)
+                waiting = lds_wait(lflag + 2 * kWavesPerBlock + wave - 1, k, a.status, a.host_status);
             if (wait_prev || wait_next) {
                 if (waiting && wait_prev) waiting = wait_progress(a.progress + (int64_t)(ri - 1) * kProgressStride, k, a.status, a.host_status);
-                if (waiting && wait_next) waiting = wait_progress(a.progress + (int64_t)(ri + 1) * kProgressStride, k, a.status, a.host_status);
+                // ... and the run after it the blocks this run's last frames read.  With flags that is
+                // its HEADS word, raised a few frames into its iteration: this run never waits for a
+                // run that is behind it
+                if (waiting && wait_next)
+                    waiting = wait_progress(a.progress + (int64_t)(ri + 1) * kProgressStride + (kFlags ? kProgressHeads : 0), k,
+                                            a.status, a.host_status);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
@@ -374,13 +427,17 @@ gl_engine_kernel(IterArgs a) {
             }
             GLV_SCHED_FENCE();
             e.template preload_lin<SC>(a);
-            if (e.deposit_out != nullptr) e.publish_preload(mine);
+            if (e.deposit_out != nullptr) {
+                e.publish_preload(mine);
+                if (kFlags) lds_raise(lflag + wave, k + 1, lane);
+            }
             GLV_SCHED_FENCE();
         } else if (live) {
             e.template preload_lin<SC>(a);
             e.publish_preload(mine);
         }
-        __syncthreads();
+        // (with flags: once, so that every wave holds its tables in registers before the first deposit)
+        if (!kFlags || k == 0) __syncthreads();
         // the next run, if it continues this utterance inside this workgroup
         if (!kPersist && wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
             const int next_utt = __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt);
@@ -414,6 +471,19 @@ gl_engine_kernel(IterArgs a) {
             else if (t == prio_q3) __builtin_amdgcn_s_setprio(0);
         }
         GLV_STAMP(4 + t - e.run.t_begin)
+        if constexpr (kFlags) {
+            // the first frame that takes a block from the next run's published preload
+            if (e.deposit_in != nullptr && waiting && (t == e.run.t_end - Eng::R + 1 || (t == e.run.t_begin && t > e.run.t_end - Eng::R + 1)))
+                waiting = lds_wait(lflag + wave + 1, k + 1, a.status, a.host_status);
+            // this run's first R-1 blocks left two frames ago: by now they have arrived, and the
+            // wait costs nothing that the frame's own loads would not cost it anyway
+            if (wait_prev && t == e.run.t_begin + Eng::R) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride + kProgressHeads, k + 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (MODE == MODE_TRAFFIC) {
             e.traffic_frame(a, t);
             continue;
@@ -477,6 +547,10 @@ gl_engine_kernel(IterArgs a) {
             wave_sync();
             e.ph6(a, t, xb);
             wave_sync();
+            if constexpr (kFlags) {
+                if (e.deposit_out != nullptr && t == e.run.t_begin + Eng::R - 2)
+                    lds_raise(lflag + kWavesPerBlock + wave, k + 1, lane);
+            }
             continue;
         } else if (MODE != MODE_ISTFT) {
             e.ph0(a, t, xb);
@@ -510,16 +584,27 @@ gl_engine_kernel(IterArgs a) {
         e.ph6(a, t, xb);
         wave_sync();
     }
-    if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
+    if constexpr (kFlags) {
+        // the deposits this wave's tails need were made by the next run frames ago
+        if (e.deposit_in != nullptr && waiting)
+            waiting = lds_wait(lflag + kWavesPerBlock + wave + 1, k + 1, a.status, a.host_status);
+    } else {
+        if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
+    }
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
     if constexpr (kPersist) {
         if (k + 1 < n_outer) enter_iteration<kNzh>(a, e, g_cur, k + 1);
         // every store of this iteration has left (the blocks other workgroups read went out
-        // written through); only then does the run's progress word rise
+        // written through); only then do the run's progress words and its flag word rise
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((wait_prev || wait_next) && lane == 0)
-            __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride, k + 1, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        if ((wait_prev || wait_next) && lane == 0) {
+            __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (a run too short to have raised its heads word inside the frame loop)
+            if (kFlags && wait_prev)
+                __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride + kProgressHeads, k + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (kFlags) lds_raise(lflag + 2 * kWavesPerBlock + wave, k + 1, lane);
         if (kEndBarrier) __syncthreads();
 #ifdef GLV_WAVE_TIMES
         GLV_STAMP(3)
