@@ -1244,19 +1244,22 @@ def test_long_form_time_sharded_at_full_size(voc, O, lj001):
     chain.close()
 
 
-@pytest.mark.parametrize("hop,win,lens,fpr", [(256, 1024, [430] * 64, 0), (256, 1024, [150, 33, 64, 7, 2, 97], 0),
-                                              (256, 1024, [150, 33, 64, 7, 2, 97], 5), (512, 800, [120, 60, 33], 0),
-                                              (256, 1024, [300] * 16 + [111] * 9, 0)])
-def test_all_iterations_in_one_launch(voc, hop, win, lens, fpr):
-    """Option "persistent" (n_fft 1024): when the runs of a call are resident on the device together,
+@pytest.mark.parametrize("n_fft,hop,win,lens,fpr", [
+    (1024, 256, 1024, [430] * 64, 0), (1024, 256, 1024, [150, 33, 64, 7, 2, 97], 0),
+    (1024, 256, 1024, [150, 33, 64, 7, 2, 97], 5), (1024, 512, 800, [120, 60, 33], 0),
+    (1024, 256, 1024, [300] * 16 + [111] * 9, 0), (1024, 128, 1024, [90, 41, 8], 0),
+    (2048, 256, 2048, [865] * 12, 0), (2048, 256, 2048, [200, 120, 60, 33, 7, 2], 9), (2048, 512, 2048, [100, 37], 0)])
+def test_all_iterations_in_one_launch(voc, n_fft, hop, win, lens, fpr):
+    """Option "persistent": when the runs of a call are resident on the device together,
     ONE launch carries all iterations - a wave keeps its run, runs whose boundary blocks travel
-    through memory wait for their neighbours' progress words, the blocks behind a run's last frame
-    come from LDS so the frame loop reads no tail buffer.  The same additions in the same order as
+    through memory wait for their neighbours' progress words; at n_fft 1024 the blocks behind a
+    run's last frame come from LDS so the frame loop reads no tail buffer, at n_fft 2048 every
+    boundary goes through memory.  The same additions in the same order as
     one launch per iteration: waveforms must be identical bit for bit, from mel input (bins that
     are zero for good left out) and from caller magnitudes (all bins), with drawn and explicit
     phases, for 1, 2, 3, 8 and 60 iterations (60: vocoder/mel_audio.py:126) - and the call must
     really have taken one launch, and no wait may have run out."""
-    n_fft, f = 1024, 513
+    f = n_fft // 2 + 1
     t_max, b = max(lens), len(lens)
     rng = np.random.default_rng(61)
     mel = np.stack([np.pad(synthetic_mel(700 + i, t), ((0, t_max - t), (0, 0))) for i, t in enumerate(lens)])

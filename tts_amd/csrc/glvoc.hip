@@ -242,15 +242,10 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, false>), g, b, lds, st, a);
-    } else if (mode == MODE_ITER_LIN_P || mode == MODE_ITER_LIN_Z_P) {
-        if constexpr (A == 1) {
-            if (mode == MODE_ITER_LIN_P)
-                hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>), g, b, lds, st, a);
-            else
-                hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>), g, b, lds, st, a);
-        } else {
-            return hipErrorInvalidDeviceFunction;
-        }
+    } else if (mode == MODE_ITER_LIN_P) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER_LIN_Z_P) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>), g, b, lds, st, a);
     } else if (mode == MODE_TRAFFIC_LIN) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_TRAFFIC_LIN, false>), g, b, lds, st, a);
     } else if (mode == MODE_TRAFFIC_LIN_Z) {
@@ -275,7 +270,7 @@ int engine_blocks_per_cu_t() {
 // the same for the iteration-spanning kernels (variant 0: all bins, 1: zero-skip)
 template <int A, int HB>
 int persist_blocks_per_cu_t(int variant) {
-    if constexpr (A == 1) {
+    {
         const size_t lds = engine_lds_bytes<A, HB>();
         int n = 0;
         const hipError_t e =
@@ -285,8 +280,6 @@ int persist_blocks_per_cu_t(int variant) {
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>,
                                                                64 * kWavesPerBlock, lds);
         return e == hipSuccess && n > 0 ? n : 0;
-    } else {
-        return 0;  // the iteration-spanning kernels exist for n_fft 1024 only
     }
 }
 
@@ -1137,7 +1130,8 @@ struct MagnitudeSource {
 // can this call's loop run as one iteration-spanning launch?  (variant: 0 all bins, 1 zero-skip)
 bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter) {
     if (p->persistent <= 0 || !lin_runs || with_sc || n_iter < 1) return false;
-    if (p->traffic_only || p->alias_utts || p->recompute || !p->cur_deposit) return false;
+    if (p->traffic_only || p->alias_utts || p->recompute) return false;
+    if (p->A == 1 && !p->cur_deposit) return false;  // (n_fft 1024: built on the producer-completed boundaries)
     const int variant = p->cur_nzh == 4 * p->A ? 0 : 1;
     if ((size_t)p->n_runs > p->progress_runs || p->persist_capacity[variant] <= 0) return false;
     return p->persistent == 2 || (int64_t)engine_grid(p) <= (int64_t)p->persist_capacity[variant];

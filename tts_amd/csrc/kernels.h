@@ -202,7 +202,7 @@ gl_engine_kernel(IterArgs a) {
     constexpr bool kCanDeposit = (kLin || MODE == MODE_ISTFT) && !SC && A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
     // (GLV_PERSIST_TWR = 2: the iteration-spanning kernels read the second pass's twiddles from
     // LDS, which saves them 16 registers; 1: in registers like the other kernels)
-    using Eng = Engine<A, HB, kPersist ? GLV_PERSIST_TWR : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist>;
+    using Eng = Engine<A, HB, kPersist ? GLV_PERSIST_TWR : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist && A == 1>;
     constexpr int kSpan = table_span<A, HB>();
     static_assert(!kCanDeposit || deposit_offset<A>() + (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= kSpan,
                   "the deposits of a workgroup must fit the table region");
@@ -334,7 +334,7 @@ gl_engine_kernel(IterArgs a) {
     if constexpr (kPersist) {
         // the blocks after the run's last frame always come from LDS: the next run's published
         // preload, or this run's own (preload_next); slot wave + 1 either way
-        e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
+        if (A == 1) e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
         enter_iteration<kNzh>(a, e, g_cur, 0);
     }
     // (not a loop at all unless the kernel spans iterations: inside a loop the compiler hoists every
@@ -446,6 +446,8 @@ gl_engine_kernel(IterArgs a) {
     }
 #if !GLV_EARLY_PREFETCH
     if (kPersist) {
+        // (n_fft 2048: no boundary blocks in LDS; every boundary goes through memory, both halves)
+        if (!kShare) e.template preload_lin<SC>(a);
         e.prefetch_block_pair(a, e.run.t_begin);
         e.template prefetch_s_pair<kNzh>(a, e.run.t_begin);
     }
