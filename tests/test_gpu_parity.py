@@ -1292,6 +1292,32 @@ def test_all_iterations_in_one_launch(voc, n_fft, hop, win, lens, fpr):
     plan.close()
 
 
+@pytest.mark.parametrize("lens", [[430], [96, 33, 7, 2, 150]])
+def test_one_frame_per_wave_in_one_launch(voc, lens):
+    """The one-frame-per-wave form (small batches) with all iterations in one launch (n_fft 1024):
+    a wave keeps its frame, writes its R blocks through to memory and raises the frame's progress
+    word; before the next iteration it waits for the words of the 2(R-1) frames whose blocks
+    overlap its own.  Same bits as one launch per iteration, for 1, 2, 3 and 60 iterations."""
+    t_max, b = max(lens), len(lens)
+    mel = np.stack([np.pad(synthetic_mel(900 + i, t), ((0, t_max - t), (0, 0))) for i, t in enumerate(lens)])
+    plan = voc.GriffinLimPlan(1024, 256, 1024, 80, t_max, b)
+    plan.set_mel_basis(22050, 0.0, 8000)
+    plan.set_option("single_frame", 1)
+    assert plan.persistent_capacity(2) > 0
+    got = {}
+    for persistent in (2, 0):   # (2: also where the library would not choose it by itself)
+        plan.set_option("persistent", persistent)
+        for k in (1, 2, 3, 60):
+            got[persistent, k] = plan.mel_to_audio(dev(mel), MEAN, STD, lens, seed=5, n_iter=k).clone()
+            assert plan.last_loop_launches() == (1 if persistent else k)
+    torch.cuda.synchronize()
+    plan.status()
+    for k in (1, 2, 3, 60):
+        assert float(got[2, k].abs().max()) > 0
+        assert torch.equal(got[2, k], got[0, k]), k
+    plan.close()
+
+
 def test_a_launch_that_is_not_resident_as_a_whole_is_reported(voc):
     """The iteration-spanning launch needs its workgroups on the device together.  Forced (option
     "persistent" = 2, a test aid) on ONE long utterance cut into twice as many workgroups as fit,

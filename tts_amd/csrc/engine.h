@@ -104,7 +104,10 @@ enum Mode {
     // keeps its run for the whole call and runs whose boundary blocks travel through memory wait
     // for their neighbours' progress words (see "iteration-spanning" in kernels.h)
     MODE_ITER_LIN_P = 12,
-    MODE_ITER_LIN_Z_P = 13
+    MODE_ITER_LIN_Z_P = 13,
+    // MODE_ITER1 with all iterations of a call in one launch: a wave keeps its frame and waits,
+    // before every iteration, for the progress words of the 2(R-1) frames around it
+    MODE_ITER1_P = 14
 };
 
 struct IterArgs {
@@ -1180,6 +1183,8 @@ struct Engine {
         F::fwd_a(v, tab, w, lane, twa_regs());
     }
     // phase 6 of a single-frame wave: last inverse pass, window, the frame's R blocks go out
+    // (SHARED: the neighbouring frames' waves read these blocks within the same launch, st_shared)
+    template <bool SHARED = false>
     GLV_HD void ph6_single(const IterArgs& a, int t, const cf* r) {
         F::inv_a(v, tab, r, lane, twa_regs());
         cf wtab[E];
@@ -1198,10 +1203,20 @@ struct Engine {
             for (int i = 0; i < HB; ++i) {
                 const int row = q * HB + i;
                 if (A == 1) {
-                    st_stream(reinterpret_cast<cf*>(p + ROW * i + 2 * lane), v[row]);
+                    cf* dst = reinterpret_cast<cf*>(p + ROW * i + 2 * lane);
+                    if (SHARED)
+                        st_shared(dst, v[row]);
+                    else
+                        st_stream(dst, v[row]);
                 } else {
                     const cf lo = v[row], hi = v[row + 8 * (A - 1)];
-                    st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
+                    if (SHARED) {
+                        cf* dst = reinterpret_cast<cf*>(p + ROW * i + 4 * lane);
+                        st_shared(dst, lo);
+                        st_shared(dst + 1, hi);
+                    } else {
+                        st_stream(reinterpret_cast<f4*>(p + ROW * i + 4 * lane), f4{lo.x, lo.y, hi.x, hi.y});
+                    }
                 }
             }
         }

@@ -78,7 +78,8 @@ struct glv_plan {
     // are resident together: -1 = off for good (a launch timed out), 0 = off, 1 = on.
     int persistent = 1;         // (2: even when the launch cannot be resident as a whole - a test aid)
     int last_loop_launches = 0; // kernel launches the iteration loop of the last call took
-    int persist_capacity[2] = {0, 0};  // workgroups seen resident together, per kernel (all bins / zero-skip)
+    int persist_capacity[3] = {0, 0, 0};  // workgroups seen resident together, per kernel (run kernels with
+                                          //   all bins / zero-skip, one frame per wave)
     int* d_progress = nullptr;         // status word (one stride) followed by the runs' progress words
     size_t progress_runs = 0;          // runs the progress words are laid out for
     int* h_status = nullptr;           // pinned, device-visible: raised by a wave whose wait ran out; sticky
@@ -242,6 +243,8 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, true>), g, b, lds, st, a);
         else
             hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z, false>), g, b, lds, st, a);
+    } else if (mode == MODE_ITER1_P) {
+        hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1_P, false>), g, b, lds, st, a);
     } else if (mode == MODE_ITER_LIN_P) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>), g, b, lds, st, a);
     } else if (mode == MODE_ITER_LIN_Z_P) {
@@ -277,7 +280,10 @@ int persist_blocks_per_cu_t(int variant) {
             variant == 0
                 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>,
                                                                64 * kWavesPerBlock, lds)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>,
+            : variant == 1
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>,
+                                                               64 * kWavesPerBlock, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gl_engine_kernel<A, HB, MODE_ITER1_P, false>,
                                                                64 * kWavesPerBlock, lds);
         return e == hipSuccess && n > 0 ? n : 0;
     }
@@ -689,7 +695,11 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
     p->progress_runs = (size_t)p->n_cus * 8 * kWavesPerBlock;
     PLAN_TRY(dmalloc(p, &p->d_progress, (1 + p->progress_runs) * kProgressStride));
     PLAN_TRY(hipDeviceSynchronize());
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
+        // (one frame per wave at n_fft 2048: handing a frame's 8 KB to fourteen neighbours costs
+        // more than the launch boundary it removes - 15.3 against 14.4 us per iteration for one
+        // 865-frame utterance - so that form keeps its launch per iteration)
+        if (variant == 2 && p->A != 1) continue;
         int per_cu = std::min(8, p->persist_blocks_per_cu(variant));
         for (; per_cu > 0 && p->persist_capacity[variant] == 0; --per_cu) {
             const int grid = per_cu * p->n_cus;
@@ -700,7 +710,8 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
             a.progress = p->d_progress + kProgressStride;
             a.status = p->d_progress;
             a.host_status = p->h_status_dev;
-            PLAN_TRY(p->launch_engine(variant == 0 ? MODE_ITER_LIN_P : MODE_ITER_LIN_Z_P, false, a, (size_t)grid, nullptr));
+            PLAN_TRY(p->launch_engine(variant == 0 ? MODE_ITER_LIN_P : variant == 1 ? MODE_ITER_LIN_Z_P : MODE_ITER1_P, false,
+                                      a, (size_t)grid, nullptr));
             PLAN_TRY(hipDeviceSynchronize());
             int seen[2] = {0, 0};
             PLAN_TRY(hipMemcpy(seen, p->d_progress + kProgressStride, sizeof(seen), hipMemcpyDeviceToHost));
@@ -870,7 +881,7 @@ extern "C" int glv_plan_status(glv_plan* p) {
 extern "C" int glv_plan_last_loop_launches(const glv_plan* p) { return p ? p->last_loop_launches : 0; }
 
 extern "C" int glv_plan_persistent_capacity(const glv_plan* p, int variant) {
-    return p && variant >= 0 && variant < 2 ? p->persist_capacity[variant] : 0;
+    return p && variant >= 0 && variant < 3 ? p->persist_capacity[variant] : 0;
 }
 
 extern "C" int glv_plan_set_inverse_basis(glv_plan* p, const float* pinv_host) {
@@ -1127,8 +1138,16 @@ struct MagnitudeSource {
     float mean = 0.f, std_ = 1.f;
 };
 
-// can this call's loop run as one iteration-spanning launch?  (variant: 0 all bins, 1 zero-skip)
-bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter) {
+// can this call's loop run as one iteration-spanning launch?  (variant: 0 all bins, 1 zero-skip,
+// 2 one frame per wave)
+bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter, bool single = false) {
+    if (single) {
+        if (p->persistent <= 0 || with_sc || n_iter < 1 || (size_t)p->n_runs > p->progress_runs) return false;
+        // (worth it only while every workgroup has a compute unit to itself: one 430-frame
+        // utterance 6.3 -> 5.9 us per iteration, four of them 10.6 -> 14.7)
+        return p->persist_capacity[2] > 0 &&
+               (p->persistent == 2 || (int64_t)engine_grid(p) <= (int64_t)std::min(p->persist_capacity[2], p->n_cus));
+    }
     if (p->persistent <= 0 || !lin_runs || with_sc || n_iter < 1) return false;
     if (p->traffic_only || p->alias_utts || p->recompute) return false;
     if (p->A == 1 && !p->cur_deposit) return false;  // (n_fft 1024: built on the producer-completed boundaries)
@@ -1138,11 +1157,20 @@ bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter)
 }
 
 // all n_iter iterations as ONE launch: progress words cleared, then the kernel
-int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, hipStream_t st) {
+int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, hipStream_t st, bool single = false) {
     HIP_TRY(hipMemsetAsync(p->d_progress, 0, (size_t)(1 + p->n_runs) * kProgressStride * sizeof(int), st));
     IterArgs a = iter_args(p, frames_stride);
     a.cmom = cmom;
     a.n_iter = n_iter;
+    if (single) {
+        // one frame per wave: the kernel alternates between the two generations of partial sums
+        set_parts_io(p, a, 0, 1);
+        a.status = p->d_progress;
+        a.progress = p->d_progress + kProgressStride;
+        a.host_status = p->h_status_dev;
+        HIP_TRY(p->launch_engine(MODE_ITER1_P, false, a, engine_grid(p), st));
+        return GLV_OK;
+    }
     for (int g = 0; g < 3; ++g) {
         a.gen_main[g] = p->d_ym[g];
         a.gen_tail[g] = p->d_yt[g];
@@ -1256,8 +1284,8 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     // (glv_plan_status reports it); from now on the loop is launched one iteration at a time
     if (p->persistent > 0 && p->h_status && *(volatile int*)p->h_status != 0) p->persistent = -1;
     p->last_loop_launches = n_iter;
-    if (n_iter > 0 && persistent_fits(p, lin_runs, with_sc, n_iter)) {
-        rc = enqueue_persistent(p, frames_stride, n_iter, cmom, st);
+    if (n_iter > 0 && persistent_fits(p, lin_runs, with_sc, n_iter, single)) {
+        rc = enqueue_persistent(p, frames_stride, n_iter, cmom, st, single);
         if (rc != GLV_OK) return rc;
         p->last_loop_launches = 1;
     } else if (n_iter > 0) {

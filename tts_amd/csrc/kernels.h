@@ -196,13 +196,15 @@ gl_engine_kernel(IterArgs a) {
     // registers (the default iteration kernels have the room anyway), so that after the set-up
     // the table region of LDS is free to hold the deposits.
     // all iterations of the call in this launch (the frame loop below runs once per iteration)
-    constexpr bool kPersist = MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P;
+    constexpr bool kPersist1 = MODE == MODE_ITER1_P;  // ... of the one-frame-per-wave form
+    constexpr bool kPersist = MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P || kPersist1;
     constexpr bool kLin = MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN ||
-                          MODE == MODE_TRAFFIC_LIN_Z || kPersist;
+                          MODE == MODE_TRAFFIC_LIN_Z || (kPersist && !kPersist1);
     constexpr bool kCanDeposit = (kLin || MODE == MODE_ISTFT) && !SC && A == 1 && GLV_DEPOSIT && kWavesPerBlock > 1;
     // (GLV_PERSIST_TWR = 2: the iteration-spanning kernels read the second pass's twiddles from
     // LDS, which saves them 16 registers; 1: in registers like the other kernels)
-    using Eng = Engine<A, HB, kPersist ? GLV_PERSIST_TWR : (((kLin && !SC) || kCanDeposit) ? 1 : 0), kPersist && A == 1>;
+    using Eng = Engine<A, HB, kPersist1 ? 0 : kPersist ? GLV_PERSIST_TWR : (((kLin && !SC) || kCanDeposit) ? 1 : 0),
+                       kPersist && !kPersist1 && A == 1>;
     constexpr int kSpan = table_span<A, HB>();
     static_assert(!kCanDeposit || deposit_offset<A>() + (kWavesPerBlock - 1) * Eng::kShareFloats / 2 <= kSpan,
                   "the deposits of a workgroup must fit the table region");
@@ -243,7 +245,7 @@ gl_engine_kernel(IterArgs a) {
     }
     // the waves' flag words (iteration-spanning kernels), behind the shared boundary blocks
     int* lflag = nullptr;
-    if constexpr (kPersist) {
+    if constexpr (kPersist && !kPersist1 && A == 1 && GLV_PERSIST_FLAGS) {
         lflag = reinterpret_cast<int*>(tables + table_span<A, HB>() + kWavesPerBlock * G::XBUF +
                                        (kWavesPerBlock + 1) * (Engine<A, HB>::kShareFloats / 2));
         if (threadIdx.x < 3 * kWavesPerBlock) lflag[threadIdx.x] = 0;
@@ -260,7 +262,7 @@ gl_engine_kernel(IterArgs a) {
     constexpr bool kShare = kLin && !SC && A == 1 && GLV_SHARE_BOUNDARY;
     // iteration-spanning kernels whose waves exchange blocks through LDS or through this CU's own
     // stores: one more barrier separates an iteration's last stores from the next one's first loads
-    constexpr bool kFlags = kPersist && GLV_PERSIST_FLAGS;
+    constexpr bool kFlags = kPersist && !kPersist1 && A == 1 && GLV_PERSIST_FLAGS;
     constexpr bool kEndBarrier = kPersist && (kShare || kCanDeposit) && !kFlags;
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
@@ -318,7 +320,7 @@ gl_engine_kernel(IterArgs a) {
     // once they have left, and the reader waits for that word before an iteration's first load,
     // then drops this CU's cached copies of anything older.
     bool wait_prev = false, wait_next = false;
-    if (kPersist) {
+    if (kPersist && !kPersist1) {
         wait_prev = rd.t_begin > 0 && e.deposit_out == nullptr;
         wait_next = rd.t_end < rd.n_frames && e.deposit_in == nullptr;
         e.heads_shared = wait_prev;
@@ -327,11 +329,14 @@ gl_engine_kernel(IterArgs a) {
     bool waiting = true;  // false once a wait has run out
     int g_cur = 0;        // generation the coming iteration reads
     constexpr bool kRc = MODE == MODE_ITER_RC || MODE == MODE_ITER_RC_FIRST;
-    constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1;
+    constexpr bool kSingle = MODE == MODE_ITER1 || MODE == MODE_ISTFT1 || kPersist1;
     // mirrors of a lane's pairs whose magnitude can be non-zero: all, or the upper half
     constexpr int kNzh =
         (MODE == MODE_ITER_LIN_Z || MODE == MODE_TRAFFIC_LIN_Z || MODE == MODE_ITER_LIN_Z_P) ? Eng::NP / 2 : Eng::NP;
-    if constexpr (kPersist) {
+    // one frame per wave: the two generations of partial-sum buffers, swapped every iteration
+    const float* parts_even = a.part_in;
+    float* parts_odd = a.part_out;
+    if constexpr (kPersist && !kPersist1) {
         // the blocks after the run's last frame always come from LDS: the next run's published
         // preload, or this run's own (preload_next); slot wave + 1 either way
         if (A == 1) e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
@@ -350,7 +355,34 @@ gl_engine_kernel(IterArgs a) {
     if (kPersist) stamp_on = k == a.n_iter / 2;
     if (kPersist) { GLV_STAMP(0) }
 #endif
-    if (kPersist) {
+    if constexpr (kPersist1) {
+        a.part_in = (k & 1) ? parts_odd : parts_even;
+        a.part_out = (k & 1) ? const_cast<float*>(parts_even) : parts_odd;
+        a.has_prev = k > 0;
+        if (k > 0 && waiting) {
+            // lane l looks at frame t - (R-1) + l: every frame whose blocks overlap this one's must
+            // have stored iteration k - 1 (and, with that, have read what this wave now overwrites)
+            const int d = lane - (Eng::R - 1), tn = e.run.t_begin + d;
+            const bool look = lane < 2 * Eng::R - 1 && d != 0 && tn >= 0 && tn < e.run.n_frames;
+            const int* word = a.progress + (int64_t)(ri + (look ? d : 0)) * kProgressStride;
+            int spins = 0;
+            for (;; ++spins) {
+                const bool ok = !look || poll_word(word) >= k;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (spins >= GLV_SPIN_LIMIT || ((spins & 255) == 255 && poll_word(a.status) != 0)) {
+                    if (spins >= GLV_SPIN_LIMIT && lane == 0) {
+                        atomicOr(a.status, 1);
+                        __hip_atomic_fetch_or(a.host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    waiting = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (kPersist && !kPersist1) {
         if (k > 0) {
             e.begin_iteration();
             // the run before this one has stored its part of the boundary blocks (iteration k - 1):
@@ -375,7 +407,7 @@ gl_engine_kernel(IterArgs a) {
     if (kSingle) {
         // one frame per wave: the run is the frame
         const int t = e.run.t_begin;
-        if (MODE == MODE_ITER1) {
+        if (MODE == MODE_ITER1 || kPersist1) {
             e.template ph0_single<true>(a, t, xb);
             GLV_STAMP(4)
             wave_sync();
@@ -402,8 +434,8 @@ gl_engine_kernel(IterArgs a) {
         e.ph5_write(xb);
         wave_sync();
         GLV_STAMP(6)
-        e.ph6_single(a, t, xb);
-        GLV_STAMP(3)
+        e.template ph6_single<kPersist1>(a, t, xb);
+        if (!kPersist1) { GLV_STAMP(3) }
     }
     if (!kSingle && !kLin && MODE != MODE_ISTFT) {
         e.preload(a);
@@ -445,7 +477,7 @@ gl_engine_kernel(IterArgs a) {
         }
     }
 #if !GLV_EARLY_PREFETCH
-    if (kPersist) {
+    if (kPersist && !kPersist1) {
         // (n_fft 2048: no boundary blocks in LDS; every boundary goes through memory, both halves)
         if (!kShare) e.template preload_lin<SC>(a);
         e.prefetch_block_pair(a, e.run.t_begin);
@@ -594,7 +626,12 @@ gl_engine_kernel(IterArgs a) {
         if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
     }
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
-    if constexpr (kPersist) {
+    if constexpr (kPersist1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(a.progress + (int64_t)ri * kProgressStride, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (kPersist && !kPersist1) {
         if (k + 1 < n_outer) enter_iteration<kNzh>(a, e, g_cur, k + 1);
         // every store of this iteration has left (the blocks other workgroups read went out
         // written through); only then do the run's progress words and its flag word rise
