@@ -51,14 +51,10 @@
 // ... and with a value that has to be in its register by then (pins the arithmetic producing
 // it, and the loads that feeds, in front of the fence)
 #define GLV_PIN(x) asm volatile("" : "+v"(x)::"memory")
-// the same for a wave-uniform value: it is computed here, in program order, not pages earlier
-// together with every other one of its kind (which then fight over the scalar registers)
-#define GLV_PIN_S(x) asm volatile("" : "+s"(x))
 #else
 #define GLV_SCHED_FENCE() ((void)0)
 #define GLV_MEM_FENCE() ((void)0)
 #define GLV_PIN(x) ((void)0)
-#define GLV_PIN_S(x) ((void)0)
 #endif
 namespace glv {
 
@@ -1129,7 +1125,6 @@ struct Engine {
                 const bool ok = valid && tc >= 0 && tc < run.n_frames;
                 const float* p = ok ? a.part_in + (int64_t)(tc & (R - 1)) * a.part_stride + utt_off + (int64_t)j * H
                                     : a.zeros;
-                GLV_PIN_S(p);
                 cf part[HV];
 #pragma unroll
                 for (int i = 0; i < HB; ++i) load_row(p, i, part);
