@@ -643,8 +643,8 @@ def main():
                                        f"batch-sharded x{world}, final device-side gather" if config3 else
                                        f"batch-sharded x{world}, no data-path collective")},
             "roofline": {"bound": "hbm",
-                         "kernel": (f"gl_persist_kernel<n_fft {N_FFT}, hop {HOP}> (all {N_ITER} iterations in one launch)"
-                                    if iters_per_launch > 1 else
+                         "kernel": (f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration-spanning> (all {N_ITER} "
+                                    f"iterations in one launch)" if iters_per_launch > 1 else
                                     f"gl_engine_kernel<n_fft {N_FFT}, hop {HOP}, iteration>"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -33,21 +33,41 @@ def short(name):
     return name[:60]
 
 
+def is_spanning(name):
+    """gl_engine_kernel<A, HB, MODE, SC> with MODE 12 / 13 / 14: all iterations of a call in one launch."""
+    return "gl_engine_kernel" in name and name.rstrip(">").endswith(("12, false", "13, false", "14, false"))
+
+
 def main():
     outdir, tag = sys.argv[1], sys.argv[2]
     lines = [f"# rocprofv3 summary {tag}", ""]
     summary = {}
-    stats = find(outdir, "kt", "kernel_stats.csv")
-    if stats:
-        lines += ["## kernel-trace --stats", "", "| kernel | calls | total ms | avg us | min us | max us | % |",
-                  "|---|---|---|---|---|---|---|"]
-        with open(stats) as fh:
+    # per-kernel statistics from the dispatch trace itself (not rocprofv3's own table), because
+    # the iteration-spanning kernels are also launched once per plan as a residency census
+    # (microseconds, nothing computed): those dispatches are left out of their rows
+    trace = find(outdir, "kt", "kernel_trace.csv")
+    if trace:
+        durs = defaultdict(list)
+        with open(trace) as fh:
             for row in csv.DictReader(fh):
-                name = short(row["Name"])
-                avg_us = float(row["AverageNs"]) / 1e3
-                lines.append(f"| {name} | {row['Calls']} | {float(row['TotalDurationNs'])/1e6:.3f} | {avg_us:.2f} | "
-                             f"{float(row['MinNs'])/1e3:.2f} | {float(row['MaxNs'])/1e3:.2f} | {float(row['Percentage']):.2f} |")
-                summary.setdefault("kernels", {})[name] = {"calls": int(row["Calls"]), "avg_us": avg_us}
+                durs[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+        total = 0.0
+        rows = []
+        for name, d in durs.items():
+            census = 0
+            if is_spanning(name):
+                keep = [x for x in d if x >= 0.2 * max(d)]
+                census, d = len(d) - len(keep), keep
+            rows.append((name, d, census))
+            total += sum(d)
+        lines += ["## kernel trace", "", "| kernel | calls | total ms | avg us | median us | min us | max us | % |",
+                  "|---|---|---|---|---|---|---|---|"]
+        for name, d, census in sorted(rows, key=lambda r: -sum(r[1])):
+            note = f" (+{census} census launches left out)" if census else ""
+            med = sorted(d)[len(d) // 2]
+            lines.append(f"| {name}{note} | {len(d)} | {sum(d)/1e3:.3f} | {sum(d)/len(d):.2f} | {med:.2f} | {min(d):.2f} | "
+                         f"{max(d):.2f} | {100 * sum(d) / total:.2f} |")
+            summary.setdefault("kernels", {})[name] = {"calls": len(d), "avg_us": sum(d) / len(d), "median_us": med}
         lines.append("")
     # the bench line printed by the profiled process itself: its HIP-event time per launch of
     # the iteration kernel, to set beside the profiler's average for the same launches
@@ -58,6 +78,9 @@ def main():
                 roof = json.loads(text)["roofline"]
                 summary["bench_under_profiler_us_per_launch"] = roof["kernel_ms_per_launch"] * 1e3
                 summary["iterations_per_launch"] = roof.get("iterations_per_launch", 1)
+                m = __import__("re").search(r"n_fft (\d+), hop (\d+)", roof["kernel"])
+                if m:
+                    summary["iter_kernel_hint"] = f"gl_engine_kernel<{int(m.group(1)) // 1024}, {int(m.group(2)) * 8 // int(m.group(1))}, "
                 # which workload, variant and kernel sources these counters belong to
                 summary["traffic_key"] = roof.get("traffic_key")
                 summary["engine_source_digest"] = roof.get("engine_source_digest")
@@ -77,26 +100,39 @@ def main():
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] == counter:
                     acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
-        per[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+        # (census launches of the iteration-spanning kernels move next to nothing: left out)
+        per[counter] = {k: (lambda w: sum(w) / len(w))([x for x in v if not is_spanning(k) or x >= 0.2 * max(v)])
+                        for k, v in acc.items()}
     if per:
         lines += ["## HBM traffic per launch (PMC, separate passes)", "",
                   "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | read MB (2x FETCH) | write MB | total MB |",
                   "|---|---|---|---|---|---|"]
         names = sorted(set(per.get("FETCH_SIZE", {})) | set(per.get("WRITE_SIZE", {})))
+        iter_rows = []
         for k in names:
             f = per.get("FETCH_SIZE", {}).get(k, 0.0)
             w = per.get("WRITE_SIZE", {}).get(k, 0.0)
             rd, wr = 2 * f * 1024 / 1e6, w * 1024 / 1e6
             lines.append(f"| {k} | {f:.0f} | {w:.0f} | {rd:.2f} | {wr:.2f} | {rd + wr:.2f} |")
-            # the iteration kernel: MODE_ITER_LIN (8) by default, MODE_ITER (0) with option linear = 0
-            # (gl_persist_kernel: all iterations of a call in one launch; bench.py's per-launch
-            # figures are per launch of whichever kernel ran)
-            if "gl_persist_kernel" in k or ("gl_engine_kernel" in k and "gl_engine_iter_kernel" not in summary and
-                                            k.rstrip(">").endswith(("8, false", "9, false", "0, false", "6, false", "4, false"))):
-                summary["gl_engine_iter_kernel"] = k
-                summary["gl_engine_iter_bytes_per_launch"] = int((rd + wr) * 1e6)
-                summary["gl_engine_iter_read_bytes"] = int(rd * 1e6)
-                summary["gl_engine_iter_write_bytes"] = int(wr * 1e6)
+            # the iteration kernel of the profiled workload: the first shape the process ran is the
+            # bench workload itself (its secondary block runs other shapes later), so the kernel
+            # with the most bytes among the candidates of the right family is taken: an
+            # iteration-spanning kernel (MODE 12 / 13) if one ran, else MODE 8 / 9 / 0 / 6 / 4
+            cand = ("gl_engine_kernel" in k and k.rstrip(">").endswith(
+                ("12, false", "13, false", " 8, false", " 9, false", " 0, false", " 6, false", " 4, false")))
+            if cand:
+                iter_rows.append((k, rd, wr))
+        want = summary.get("iter_kernel_hint")
+        pick = [r for r in iter_rows if want and want in r[0]] or iter_rows
+        if pick:
+            k, rd, wr = max(pick, key=lambda r: r[1] + r[2])
+            summary["gl_engine_iter_kernel"] = k
+            summary["gl_engine_iter_bytes_per_launch"] = int((rd + wr) * 1e6)
+            summary["gl_engine_iter_read_bytes"] = int(rd * 1e6)
+            summary["gl_engine_iter_write_bytes"] = int(wr * 1e6)
+            n_it = summary.get("iterations_per_launch", 1)
+            lines += ["", f"Iteration kernel of this workload: {k}: {rd + wr:.1f} MB per launch = "
+                      f"{(rd + wr) / n_it:.1f} MB per iteration ({n_it} iteration(s) per launch)."]
         lines.append("")
     with open(os.path.join(outdir, f"summary_{tag}.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
