@@ -263,7 +263,9 @@ gl_engine_kernel(IterArgs a) {
     // iteration-spanning kernels whose waves exchange blocks through LDS or through this CU's own
     // stores: one more barrier separates an iteration's last stores from the next one's first loads
     constexpr bool kFlags = kPersist && !kPersist1 && A == 1 && GLV_PERSIST_FLAGS;
-    constexpr bool kEndBarrier = kPersist && (kShare || kCanDeposit) && !kFlags;
+    // (n_fft 2048 too: there the waves of a workgroup exchange both halves of their boundary blocks
+    // through this CU's own plain stores)
+    constexpr bool kEndBarrier = kPersist && !kPersist1 && !kFlags;
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
     const int n_outer = kPersist ? a.n_iter : 1;
@@ -323,6 +325,15 @@ gl_engine_kernel(IterArgs a) {
     if (kPersist && !kPersist1) {
         wait_prev = rd.t_begin > 0 && e.deposit_out == nullptr;
         wait_next = rd.t_end < rd.n_frames && e.deposit_in == nullptr;
+        if (!kShare) {
+            // no boundary blocks in LDS (n_fft 2048): a neighbouring run that is a wave of this
+            // workgroup still needs no progress word - its plain stores reach this CU's loads
+            // once they have drained and the closing barrier of the iteration has been passed
+            if (wave > 0 && __builtin_amdgcn_readfirstlane(a.runs[ri - 1].utt) == rd.utt) wait_prev = false;
+            if (wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs &&
+                __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt) == rd.utt)
+                wait_next = false;
+        }
         e.heads_shared = wait_prev;
         e.tails_shared = wait_next;
     }
