@@ -308,6 +308,16 @@ int glv_shard_exchange(glv_plan* plan, void* stream);
 /* glv_shard_exchange, then n_iter times { glv_shard_step; glv_shard_exchange }: the whole loop
  * after glv_shard_begin enqueued by one call. */
 int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
+/* How the last glv_shard_run enqueued its steps and swaps (option "shard_graph" asks for a form,
+ * default 2; a plan whose capture fails stays with 0):
+ *   0  every step and every swap enqueued by the host, one stream;
+ *   1  the steps and swaps after the first swap replayed from one hipGraph;
+ *   2  the same graph with two branches: the workgroups at the shard's two edges, which alone read
+ *      what a swap brings and write what it sends, are launched apart from the workgroups between
+ *      them, so a swap overlaps the interior of the iteration after it.
+ * All three produce the same bits.  (No counterpart in the reference: vocoder/mel_audio.py:126
+ * runs one utterance on one device.) */
+int glv_shard_last_run_form(const glv_plan* plan);
 
 /*
  * Tuning and measurement hooks (no counterpart in the reference).

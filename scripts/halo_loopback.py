@@ -28,6 +28,8 @@ def main():
     chain = HaloChain(HaloChain.unique_id(), 0, 1, dev)
     plan.halo_attach(chain)
     plan.set_option("halo_loopback", 1)
+    if os.environ.get("GLV_FPR"):
+        plan.set_option("frames_per_run", int(os.environ["GLV_FPR"]))
 
     def copies():
         a, b = plan.shard_halo_pack()
@@ -48,20 +50,28 @@ def main():
             best = min(best, time.perf_counter() - t0)
         return round(1e3 * best / (n_iter + 1), 4)
 
-    def one_call():
+    waves = {}
+
+    def one_call(form):
+        plan.set_option("shard_graph", form)
         best = 1e9
-        for _ in range(4):
+        for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             plan.shard_begin(s, per_rank, 3 * per_rank, seed=3)
             plan.shard_run(n_iter, 0.99)
-            plan.shard_end()
+            y, _ = plan.shard_end()
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
+        waves[form] = (y.clone(), plan.shard_last_run_form())
         return round(1e3 * best / (n_iter + 1), 4)
 
+    by_form = {"enqueued": one_call(0), "one_graph": one_call(1), "one_graph_edges_apart": one_call(2),
+               "automatic": one_call(-1)}
     out = {"frames_per_rank": per_rank, "n_iter": n_iter,
-           "ms_per_iteration_library_rccl_loopback_one_call": one_call(),
+           "ms_per_iteration_library_rccl_loopback_one_call": by_form,
+           "forms_taken": [waves[f][1] for f in (0, 1, 2, -1)],
+           "same_bits": bool(all(torch.equal(waves[0][0], waves[f][0]) for f in (1, 2, -1))),
            "ms_per_iteration_no_swap": timed(lambda: None),
            "ms_per_iteration_device_copies": timed(copies),
            "ms_per_iteration_library_rccl_loopback": timed(plan.shard_exchange)}

@@ -1044,6 +1044,65 @@ def test_library_halo_exchange_over_rccl_to_itself(voc, n_fft, hop):
     chain.close()
 
 
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 256)])
+def test_shard_run_replayed_from_one_graph(voc, n_fft, hop):
+    """glv_shard_run enqueues the steps and swaps after the first swap one by one (option
+    "shard_graph" 0), replays them from one hipGraph (1), or from a graph with two branches in
+    which the workgroups at the shard's edges, and the swap, overlap the workgroups between them
+    (2); -1 chooses between the last two by the shard's size.  The same launches on the same data in
+    an order that keeps every dependence: the waveforms must be identical bit for bit, with the
+    swap as device copies too; a replay, a shard at another place of the utterance, another
+    iteration count and another momentum must each give what the enqueued form gives."""
+    frames, f = 1400, n_fft // 2 + 1
+    rng = np.random.default_rng(61)
+    s_all = (rng.standard_normal((frames, f)) ** 2).astype(np.float32)
+    chain = voc.HaloChain(voc.HaloChain.unique_id(), 0, 1)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, 500, 1)
+    plan.halo_attach(chain)
+    plan.set_option("halo_loopback", 1)
+
+    def run(form, t0, t1, n_iter, momentum):
+        plan.set_option("shard_graph", form)
+        plan.shard_begin(dev(s_all[t0:t1]), t0, frames, seed=17)
+        plan.shard_run(n_iter, momentum)
+        taken = plan.shard_last_run_form()
+        y, n_begin = plan.shard_end()
+        return y.clone(), n_begin, taken
+
+    def by_copies(t0, t1, n_iter, momentum):
+        plan.shard_begin(dev(s_all[t0:t1]), t0, frames, seed=17)
+        for k in range(n_iter + 1):
+            if k:
+                plan.shard_step(momentum)
+            plan.shard_halo_unpack(*plan.shard_halo_pack())
+        return plan.shard_end()[0].clone()
+
+    for t0, t1, n_iter, momentum in [(300, 800, 6, 0.99), (300, 800, 6, 0.99), (450, 930, 6, 0.99),
+                                     (450, 930, 3, 0.99), (450, 930, 3, 0.5)]:
+        y0, b0, form0 = run(0, t0, t1, n_iter, momentum)
+        assert form0 == 0 and float(y0.abs().max()) > 0
+        assert torch.equal(by_copies(t0, t1, n_iter, momentum), y0)
+        for form in (1, 2, -1):
+            y, b, taken = run(form, t0, t1, n_iter, momentum)
+            assert taken == (form if form > 0 else 1), (form, taken)   # (a small shard: one branch)
+            assert b == b0 and torch.equal(y, y0), (form, t0, n_iter, momentum)
+    # two calls on one begin: the second continues where the first ended, from a graph of its own
+    plan.set_option("shard_graph", 0)
+    plan.shard_begin(dev(s_all[300:800]), 300, frames, seed=17)
+    plan.shard_run(6, 0.99)
+    y_six = plan.shard_end()[0].clone()
+    plan.set_option("shard_graph", 2)
+    plan.shard_begin(dev(s_all[300:800]), 300, frames, seed=17)
+    plan.shard_run(2, 0.99)
+    plan.shard_step(0.99)
+    plan.shard_exchange()
+    plan.shard_run(3, 0.99)
+    assert torch.equal(plan.shard_end()[0], y_six)
+    torch.cuda.synchronize()
+    plan.close()
+    chain.close()
+
+
 @pytest.mark.parametrize("n_fft,hop,win,lens,fpr", [(1024, 256, 1024, [64, 40, 21, 2, 9], 0), (1024, 256, 1024, [150, 33], 5),
                                                     (1024, 128, 1024, [50, 12, 64], 9), (1024, 512, 1024, [40, 17], 0),
                                                     (1024, 256, 800, [70, 31, 6], 3), (2048, 256, 2048, [48, 30], 0)])

@@ -148,6 +148,9 @@ struct IterArgs {
     // Time shard: runs, frames and blocks are numbered over the whole utterance, while spec, S and
     // the overlap-add buffers hold only the shard - index 0 there is frame / block t_origin.
     int t_origin;
+    // MODE_ITER_LIN over a subset of the run table's workgroups: workgroup b of the launch takes
+    // the runs of workgroup wg_first + b * (1 + wg_skip) of the table (0, 0: all of them in order)
+    int wg_first, wg_skip;
     // Iteration-spanning kernels (MODE_ITER_LIN_P / _Z_P): iteration k reads generation k % 3 of
     // the overlap-add buffers (and (k + 2) % 3 as the older signal), writes (k + 1) % 3.
     int n_iter;

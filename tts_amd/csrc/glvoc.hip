@@ -177,6 +177,26 @@ struct glv_plan {
     glv_halo* halo = nullptr;  // not owned
     int halo_loopback = 0;     // test aid: both neighbours are this rank itself
     int shard_t0 = 0, shard_t1 = 0, shard_T = 0, shard_cur = 0, shard_k = 0;
+    // glv_shard_run as one graph: the steps and swaps after the first swap, captured once per
+    // (shard, iteration count, momentum) and replayed.  Form 2 launches the workgroups at the
+    // shard's two edges apart from those between them, so that only the edge launch waits for the
+    // swap and the swap only for the edge launch.
+    struct ShardGraph {
+        int t0, t1, T, n_runs, n_iter, cur, first, loopback, form;
+        float momentum;
+        const glv_halo* halo;
+        int end_cur, end_k;
+        hipGraphExec_t exec;
+    };
+    ShardGraph shard_graph = {};
+    int shard_graph_form = -1;     // option "shard_graph": 0 = enqueue every step and swap, 1 = one
+                                   // graph of steps and swaps in turn, 2 = one graph, edges apart,
+                                   // -1 = 2 for shards of at least two workgroups per CU, else 1
+    bool shard_graph_refused = false;  // a capture failed: this plan stays with the enqueued form
+    int shard_last_form = 0;       // form the last glv_shard_run took
+    hipStream_t shard_side = nullptr;  // capture streams and events of the graph's two branches
+    hipStream_t shard_main = nullptr;
+    hipEvent_t shard_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -247,6 +267,7 @@ hipError_t launch_engine_t(int mode, bool sc, const IterArgs& a, size_t grid, hi
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER1_P, false>), g, b, lds, st, a);
     } else if (mode == MODE_ITER_LIN_P) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_P, false>), g, b, lds, st, a);
+
     } else if (mode == MODE_ITER_LIN_Z_P) {
         hipLaunchKernelGGL((gl_engine_kernel<A, HB, MODE_ITER_LIN_Z_P, false>), g, b, lds, st, a);
     } else if (mode == MODE_TRAFFIC_LIN) {
@@ -270,7 +291,8 @@ int engine_blocks_per_cu_t() {
         n = 1;
     return n < 1 ? 1 : n;
 }
-// the same for the iteration-spanning kernels (variant 0: all bins, 1: zero-skip)
+// the same for the iteration-spanning kernels (variant 0: all bins, 1: zero-skip, 2: one frame
+// per wave)
 template <int A, int HB>
 int persist_blocks_per_cu_t(int variant) {
     {
@@ -370,12 +392,18 @@ void drop_graphs(glv_plan* p) {
     for (auto& g : p->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     p->graphs.clear();
+    if (p->shard_graph.exec) (void)hipGraphExecDestroy(p->shard_graph.exec);
+    p->shard_graph.exec = nullptr;
 }
 
 void plan_free(glv_plan* p) {
     if (!p) return;
     DeviceGuard guard(p->device);
     drop_graphs(p);
+    if (p->shard_side) (void)hipStreamDestroy(p->shard_side);
+    if (p->shard_main) (void)hipStreamDestroy(p->shard_main);
+    for (hipEvent_t e : p->shard_ev)
+        if (e) (void)hipEventDestroy(e);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->h_status) (void)hipHostFree(p->h_status);
@@ -574,6 +602,34 @@ size_t engine_grid(const glv_plan* p) { return (size_t)(p->n_runs + kWavesPerBlo
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+namespace {
+// How many workgroups of an iteration-spanning kernel (variant 0: all bins, 1: zero-skip, 2: one
+// frame per wave) are resident together: launches of falling size in which
+// every workgroup waits, bounded, to see all the others.  Synchronises the device.
+hipError_t persist_census(glv_plan* p, int variant) {
+    const int mode = variant == 0 ? MODE_ITER_LIN_P : variant == 1 ? MODE_ITER_LIN_Z_P : MODE_ITER1_P;
+    hipError_t e = hipDeviceSynchronize();
+    int per_cu = std::min(8, p->persist_blocks_per_cu(variant));
+    for (; e == hipSuccess && per_cu > 0 && p->persist_capacity[variant] == 0; --per_cu) {
+        const int grid = per_cu * p->n_cus;
+        e = hipMemset(p->d_progress, 0, (size_t)2 * kProgressStride * sizeof(int));
+        if (e != hipSuccess) break;
+        IterArgs a = iter_args(p, 1);
+        a.census = 1;
+        a.n_iter = 0;
+        a.progress = p->d_progress + kProgressStride;
+        a.status = p->d_progress;
+        a.host_status = p->h_status_dev;
+        e = p->launch_engine(mode, false, a, (size_t)grid, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        int seen[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(seen, p->d_progress + kProgressStride, sizeof(seen), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && seen[0] == grid && seen[1] == grid) p->persist_capacity[variant] = grid;
+    }
+    return e;
+}
+}  // namespace
+
 extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_length, int n_mels,
                                int max_frames, int max_batch, int device) {
     if (!out) return fail(GLV_ERR_INVALID, "out is null");
@@ -700,23 +756,7 @@ extern "C" int glv_plan_create(glv_plan** out, int n_fft, int hop, int win_lengt
         // more than the launch boundary it removes - 15.3 against 14.4 us per iteration for one
         // 865-frame utterance - so that form keeps its launch per iteration)
         if (variant == 2 && p->A != 1) continue;
-        int per_cu = std::min(8, p->persist_blocks_per_cu(variant));
-        for (; per_cu > 0 && p->persist_capacity[variant] == 0; --per_cu) {
-            const int grid = per_cu * p->n_cus;
-            PLAN_TRY(hipMemset(p->d_progress, 0, (size_t)2 * kProgressStride * sizeof(int)));
-            IterArgs a = iter_args(p, 1);
-            a.census = 1;
-            a.n_iter = 0;
-            a.progress = p->d_progress + kProgressStride;
-            a.status = p->d_progress;
-            a.host_status = p->h_status_dev;
-            PLAN_TRY(p->launch_engine(variant == 0 ? MODE_ITER_LIN_P : variant == 1 ? MODE_ITER_LIN_Z_P : MODE_ITER1_P, false,
-                                      a, (size_t)grid, nullptr));
-            PLAN_TRY(hipDeviceSynchronize());
-            int seen[2] = {0, 0};
-            PLAN_TRY(hipMemcpy(seen, p->d_progress + kProgressStride, sizeof(seen), hipMemcpyDeviceToHost));
-            if (seen[0] == grid && seen[1] == grid) p->persist_capacity[variant] = grid;
-        }
+        PLAN_TRY(persist_census(p, variant));
     }
 #undef PLAN_TRY
     if (noalloc_warm_up_current_device() != GLV_OK) {
@@ -777,6 +817,10 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
         if (p->persistent >= 0) p->persistent = value;
     } else if (!strcmp(name, "halo_loopback")) {
         p->halo_loopback = value != 0;
+    } else if (!strcmp(name, "shard_graph")) {
+        if (value < -1 || value > 2) return fail(GLV_ERR_INVALID, "shard_graph is -1 (automatic), 0, 1 or 2");
+        p->shard_graph_form = value;
+        p->shard_graph_refused = false;
     } else if (!strcmp(name, "fuse_draw")) {
         p->fuse_draw = value != 0;
     } else if (!strcmp(name, "single_frame")) {
@@ -1503,14 +1547,17 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     return GLV_OK;
 }
 
-extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
-    int rc = shard_check(p);
-    if (rc != GLV_OK) return rc;
-    if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
-    DeviceGuard guard(p->device);
+namespace {
+
+// One Griffin-Lim iteration over `grid` workgroups of the shard's run table, starting at
+// workgroup wg_first and taking every (1 + wg_skip)-th; the plan's generation counters stay as
+// they are (shard_advance moves them once all workgroups of the iteration are enqueued).
+int shard_launch(glv_plan* p, float momentum, hipStream_t st, int wg_first, int wg_skip, size_t grid) {
     IterArgs a = shard_iter_args(p);
     a.cmom = momentum / (1.0f + momentum);
     a.has_prev = p->shard_k > 0;
+    a.wg_first = wg_first;
+    a.wg_skip = wg_skip;
     if (p->linear) {
         // momentum in the time domain: the halo swap has completed both older generations, so
         // the previous signal is as local as the current one
@@ -1518,15 +1565,29 @@ extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
         set_io(p, a, cur, out);
         a.y_prev = p->d_ym[prev];
         a.y_prev_tail = p->d_yt[prev];
-        HIP_TRY(p->launch_engine(MODE_ITER_LIN, false, a, engine_grid(p), (hipStream_t)stream));
-        p->shard_cur = out;
+        HIP_TRY(p->launch_engine(MODE_ITER_LIN, false, a, grid, st));
     } else {
         set_io(p, a, p->shard_cur, p->shard_cur ^ 1);
-        HIP_TRY(p->launch_engine(MODE_ITER, false, a, engine_grid(p), (hipStream_t)stream));
-        p->shard_cur ^= 1;
+        HIP_TRY(p->launch_engine(MODE_ITER, false, a, grid, st));
     }
-    p->shard_k++;
     return GLV_OK;
+}
+
+void shard_advance(glv_plan* p) {
+    p->shard_cur = p->linear ? (p->shard_cur + 1) % 3 : p->shard_cur ^ 1;
+    p->shard_k++;
+}
+
+}  // namespace
+
+extern "C" int glv_shard_step(glv_plan* p, float momentum, void* stream) {
+    int rc = shard_check(p);
+    if (rc != GLV_OK) return rc;
+    if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
+    DeviceGuard guard(p->device);
+    rc = shard_launch(p, momentum, (hipStream_t)stream, 0, 0, engine_grid(p));
+    if (rc == GLV_OK) shard_advance(p);
+    return rc;
 }
 
 extern "C" int glv_shard_halo_samples(const glv_plan* p) { return p ? (p->R - 1) * p->hop : 0; }
@@ -1732,6 +1793,11 @@ extern "C" int glv_halo_attach(glv_plan* p, glv_halo* h) {
     if (h && h->device != p->device)
         return fail(GLV_ERR_INVALID, "the communicator lives on device %d, the plan on %d", h->device, p->device);
     p->halo = h;
+    if (p->shard_graph.exec) {  // its transfers name the communicator that was attached before
+        DeviceGuard guard(p->device);
+        (void)hipGraphExecDestroy(p->shard_graph.exec);
+        p->shard_graph.exec = nullptr;
+    }
     return GLV_OK;
 }
 
@@ -1774,20 +1840,115 @@ extern "C" int glv_shard_exchange(glv_plan* p, void* stream) {
     return GLV_OK;
 }
 
+namespace {
+
+// n_iter times { step; swap }, enqueued.  With `side` the workgroups at the shard's two edges
+// (the only ones that read what a swap brings, and the only ones whose output a swap sends) are
+// launched on `st`, followed by the swap, while the workgroups between them run on `side`: an
+// iteration's interior launch waits for both launches of the iteration before, its edge launch
+// for those and for the swap in between.  ev: interior done [2], edges done [2], fork, join.
+// (The transfers stay on the stream the capture began on: RCCL 2.26 faults when asked to add
+// them to a stream that joined the capture later.)
+int enqueue_shard_chain(glv_plan* p, int n_iter, float momentum, hipStream_t st, hipStream_t side,
+                        hipEvent_t* ev) {
+    const size_t n_wg = engine_grid(p);
+    if (!side || n_wg < 3 || !p->linear) {
+        int rc = GLV_OK;
+        for (int k = 0; k < n_iter && rc == GLV_OK; ++k) {
+            rc = glv_shard_step(p, momentum, st);
+            if (rc == GLV_OK) rc = glv_shard_exchange(p, st);
+        }
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(ev[4], st));
+    HIP_TRY(hipStreamWaitEvent(side, ev[4], 0));
+    for (int k = 0; k < n_iter; ++k) {
+        if (k > 0) {
+            HIP_TRY(hipStreamWaitEvent(side, ev[2 + ((k - 1) & 1)], 0));
+            HIP_TRY(hipStreamWaitEvent(st, ev[(k - 1) & 1], 0));
+        }
+        int rc = shard_launch(p, momentum, side, 1, 0, n_wg - 2);
+        if (rc != GLV_OK) return rc;
+        HIP_TRY(hipEventRecord(ev[k & 1], side));
+        rc = shard_launch(p, momentum, st, 0, (int)n_wg - 2, 2);
+        if (rc != GLV_OK) return rc;
+        HIP_TRY(hipEventRecord(ev[2 + (k & 1)], st));
+        shard_advance(p);
+        rc = glv_shard_exchange(p, st);
+        if (rc != GLV_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev[5], side));
+    HIP_TRY(hipStreamWaitEvent(st, ev[5], 0));
+    return GLV_OK;
+}
+
+}  // namespace
+
 extern "C" int glv_shard_run(glv_plan* p, int n_iter, float momentum, void* stream) {
     int rc = shard_check(p);
     if (rc != GLV_OK) return rc;
     if (n_iter < 0) return fail(GLV_ERR_INVALID, "n_iter must be >= 0");
+    if (momentum < 0.f) return fail(GLV_ERR_INVALID, "griffinlim() called with momentum=%g < 0", momentum);
     if (!p->halo) return fail(GLV_ERR_STATE, "glv_halo_attach has not been called");
-    // the swap that completes the initial inverse transform, then step and swap n_iter times:
-    // everything is enqueued on the one stream, the host never waits
-    rc = glv_shard_exchange(p, stream);
-    for (int k = 0; k < n_iter && rc == GLV_OK; ++k) {
-        rc = glv_shard_step(p, momentum, stream);
-        if (rc == GLV_OK) rc = glv_shard_exchange(p, stream);
+    DeviceGuard guard(p->device);
+    hipStream_t st = (hipStream_t)stream;
+    // the swap that completes the initial inverse transform (enqueued as it is: the first transfer
+    // between two ranks sets their connection up, which no capture can hold), then step and swap
+    // n_iter times; the host never waits
+    rc = glv_shard_exchange(p, st);
+    p->shard_last_form = 0;
+    if (rc != GLV_OK || n_iter == 0) return rc;
+    int form = (p->use_graph && !p->shard_graph_refused) ? p->shard_graph_form : 0;
+    // (two branches cost a few microseconds of waiting on each other per iteration: worth it once
+    // the interior launch is long enough to hide a swap behind)
+    if (form < 0) form = (int64_t)engine_grid(p) >= 2 * (int64_t)p->n_cus ? 2 : 1;
+    if (form == 0) return enqueue_shard_chain(p, n_iter, momentum, st, nullptr, nullptr);
+
+    glv_plan::ShardGraph& g = p->shard_graph;
+    const bool hit = g.exec && g.t0 == p->shard_t0 && g.t1 == p->shard_t1 && g.T == p->shard_T &&
+                     g.n_runs == p->n_runs && g.n_iter == n_iter && g.cur == p->shard_cur &&
+                     g.first == (p->shard_k == 0) && g.loopback == p->halo_loopback && g.form == form &&
+                     g.momentum == momentum && g.halo == p->halo;
+    if (!hit) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        if (!p->shard_main) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->shard_main, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&p->shard_side, hipStreamNonBlocking));
+            for (hipEvent_t& e : p->shard_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const int cur0 = p->shard_cur, k0 = p->shard_k;
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(p->shard_main, hipStreamCaptureModeRelaxed);
+        int lrc = GLV_OK;
+        if (e == hipSuccess) {
+            lrc = enqueue_shard_chain(p, n_iter, momentum, p->shard_main, form == 2 ? p->shard_side : nullptr,
+                                      p->shard_ev);
+            e = hipStreamEndCapture(p->shard_main, &graph);
+        }
+        hipGraphExec_t exec = nullptr;
+        if (e == hipSuccess && lrc == GLV_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        const int end_cur = p->shard_cur, end_k = p->shard_k;
+        p->shard_cur = cur0;
+        p->shard_k = k0;
+        if (e != hipSuccess || lrc != GLV_OK || !exec) {
+            // (an RCCL build that cannot be captured, for one): nothing of the chain has run
+            (void)hipGetLastError();
+            p->shard_graph_refused = true;
+            return enqueue_shard_chain(p, n_iter, momentum, st, nullptr, nullptr);
+        }
+        g = glv_plan::ShardGraph{p->shard_t0, p->shard_t1, p->shard_T, p->n_runs, n_iter, cur0, k0 == 0,
+                                 p->halo_loopback, form, momentum, p->halo, end_cur, end_k, exec};
     }
-    return rc;
+    HIP_TRY(hipGraphLaunch(g.exec, st));
+    p->shard_cur = g.end_cur;
+    p->shard_k = g.end_k;
+    p->shard_last_form = form;
+    return GLV_OK;
 }
+
+extern "C" int glv_shard_last_run_form(const glv_plan* p) { return p ? p->shard_last_form : 0; }
 
 namespace {
 

@@ -256,7 +256,9 @@ gl_engine_kernel(IterArgs a) {
     // wave-uniform values are forced into scalar registers: the compiler cannot see that
     // threadIdx.x >> 6 (and everything loaded through it) is the same in all 64 lanes
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ri = blockIdx.x * kWavesPerBlock + wave;
+    // (a time shard launches the workgroups at its two edges apart from those between them)
+    const int wg = (MODE == MODE_ITER_LIN && !SC) ? a.wg_first + (int)blockIdx.x * (1 + a.wg_skip) : (int)blockIdx.x;
+    const int ri = wg * kWavesPerBlock + wave;
     // kernels whose waves hand boundary blocks to each other through LDS meet at a barrier after
     // the preload: there a wave without a run has to stay until then
     constexpr bool kShare = kLin && !SC && A == 1 && GLV_SHARE_BOUNDARY;

@@ -419,6 +419,11 @@ class GriffinLimPlan:
         one library call (needs halo_attach)."""
         _lib.check(self.lib.glv_shard_run(self._handle, int(n_iter), float(momentum), _stream_ptr(self.device)))
 
+    def shard_last_run_form(self):
+        """How the last shard_run was enqueued: 0 step by step, 1 replayed from one graph, 2 from
+        one graph whose edge workgroups and swaps overlap the interior (option "shard_graph")."""
+        return int(self.lib.glv_shard_last_run_form(self._handle))
+
     def shard_end(self):
         """Returns (y_local, n_begin): this shard's samples [n_begin, n_begin + len(y_local))
         of the whole (un-normalised) waveform."""
