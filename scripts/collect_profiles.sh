@@ -55,4 +55,5 @@ PY
 for d in "$ROOT"/gpurun_out/pmc_${TAG} "$ROOT"/gpurun_out/pmc_${TAG}_*; do
   [ -f "$d/summary.json" ] && cp "$d/summary.json" "$P/$(basename "$d" | sed "s/^pmc_//")_pmc_counters.json"
 done
+[ -s "$M/halo_loopback.json" ] && tail -1 "$M/halo_loopback.json" > "$P/${TAG}_halo_overhead.jsonl"
 echo "profiles/ updated from $M"

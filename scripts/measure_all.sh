@@ -48,4 +48,7 @@ GM="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
 KERNEL_FILTER=nnls_fused_kernel BENCH_ARGS="--inversion nnls" scripts/pmc_gpu.sh "${TAG}_nnls" "$GM" > "$OUT/pmc_nnls.log" 2>&1 || { echo "pmc nnls failed"; tail -5 "$OUT/pmc_nnls.log"; exit 1; }
 # the pseudo-inverse product (mel_native_kernel): the same matrix-core counters
 KERNEL_FILTER=mel_native_kernel scripts/pmc_gpu.sh "${TAG}_melnative" "$GM" > "$OUT/pmc_melnative.log" 2>&1 || { echo "pmc mel_native failed"; tail -5 "$OUT/pmc_melnative.log"; exit 1; }
+# the time-sharded loop at the long-form shard size, RCCL loopback: enqueued, one graph, two branches
+timeout -k 10 200 python scripts/halo_loopback.py > "$OUT/halo_loopback.json" 2> "$OUT/halo_loopback.err" || { echo "halo loopback failed"; tail -5 "$OUT/halo_loopback.err"; exit 1; }
+tail -1 "$OUT/halo_loopback.json"
 echo done
