@@ -321,12 +321,16 @@ def secondary_measurements(device, mean, std):
     alg = fused_bytes_per_launch(n_fft, lens, magnitudes_per_frame(n_fft, True))
     key = traffic_key(n_fft, HOP, batch, frames, "fixed", "default")
     traffic, traffic_source = measured_traffic(key)
+    # (the counter record is per launch: with all iterations in one launch, N_ITER iterations' worth)
+    iters_per_launch = max(1, N_ITER // max(1, plan.last_loop_launches()))
     batch_line = {"workload": f"batch {batch} x {frames} frames, n_fft {n_fft}, hop {HOP}, {N_ITER} iterations "
                               f"(the reference's defaults), inputs resident in HBM",
                   "value": round(audio_s / dt, 2), "unit": "audio-sec/sec", "ms_per_step": round(1e3 * dt, 4),
-                  "steps": steps, "kernel_ms_per_launch": round(kernel_ms, 5), "alg_bytes_per_launch": alg,
+                  "steps": steps, "iterations_per_launch": iters_per_launch,
+                  "kernel_ms_per_iteration": round(kernel_ms, 5), "alg_bytes_per_iteration": alg,
                   "roofline_frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "traffic": traffic, "traffic_source": traffic_source, "traffic_key": key}
+                  "traffic_per_iteration": round(traffic / iters_per_launch) if traffic else None,
+                  "traffic_source": traffic_source, "traffic_key": key}
     plan.close()
     one = mel_host[0]
     for _ in range(5):
