@@ -85,7 +85,7 @@ def test_spectral_convergence_curve(lj001, kat, name, n_fft, frames):
     want = kat["sc_curve_rng0"][name]
     got = [sc[k - 1] for k in want["k"]]
     assert np.allclose(got, want["sc"], rtol=1e-6)
-    # four-decimal values quoted in the survey of the reference
+    # the same curve to four decimals, as first recorded for this fixture and seed
     quoted = {"n2048_t865": [0.7078, 0.3730, 0.2519, 0.1917, 0.1798, 0.1733, 0.1739],
               "n1024_t430": [0.5383, 0.3354, 0.2662, 0.2215, 0.1932, 0.1788, 0.1787]}[name]
     assert np.allclose(got, quoted, atol=6e-5)
