@@ -601,6 +601,9 @@ def main():
         unfused_bytes = sum(44 * f_bins * t + 8 * HOP * (t - 1) for t in frames_list)
         # the loop is one iteration-spanning launch where the library could make it one (every run
         # resident at once), else one launch per iteration: bytes and time are those of a LAUNCH
+        # (a batch too large for one such launch runs as several, one per group of utterances, one
+        # after the other: the figures are then those of the groups' launches taken together)
+        groups = 1 if config4 else max(1, plan.last_loop_groups())
         launches = 1 if config4 else max(1, plan.last_loop_launches())
         iters_per_launch = 1 if config4 else N_ITER // launches
         iter_ms = float(np.mean(loop_ms)) / N_ITER
@@ -658,6 +661,7 @@ def main():
                          "alg_bytes_per_launch": fused_bytes,
                          "kernel_ms_per_launch": round(kernel_ms, 5),
                          "iterations_per_launch": iters_per_launch,
+                         "utterance_groups_per_step": groups,
                          "alg_bytes_per_iteration": iter_bytes,
                          "kernel_ms_per_iteration": round(iter_ms, 5),
                          "traffic": traffic, "traffic_source": traffic_source,

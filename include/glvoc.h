@@ -385,6 +385,11 @@ int glv_plan_persistent_capacity(const glv_plan* plan, int variant);
 /* Kernel launches the iteration loop of the last Griffin-Lim call took: 1 when it ran as one
  * iteration-spanning launch, n_iter otherwise. */
 int glv_plan_last_loop_launches(const glv_plan* plan);
+/* Groups of consecutive utterances the last Griffin-Lim call was cut into (1: one piece).  A batch
+ * with more runs than one iteration-spanning launch holds runs as several such launches, one per
+ * group, one after the other; glv_plan_last_loop_launches then counts the launches of ONE group's
+ * loop.  Option "group_frames": frames per group (0 = automatic, -1 = never cut). */
+int glv_plan_last_loop_groups(const glv_plan* plan);
 
 /*
  * Writes the initial phase the library draws when a call passes phase0_dev == NULL: the unit

@@ -1045,6 +1045,58 @@ def test_library_halo_exchange_over_rccl_to_itself(voc, n_fft, hop):
 
 
 @pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 256)])
+def test_large_batch_cut_into_groups_of_utterances(voc, n_fft, hop):
+    """A batch with more runs than one iteration-spanning launch holds is cut into groups of
+    consecutive utterances, each run as such a launch with the run table that a call of those
+    utterances alone gets (option "group_frames" sets the size, here small enough to cut a small
+    batch).  Every group's rows must therefore equal, bit for bit, what a call of just that group
+    returns, and the whole must agree with the uncut batch (other run boundaries: a few sums
+    associate differently) to rounding."""
+    lens = [90, 64, 120, 33, 77, 101, 58, 96, 45, 110, 70]
+    b, t_max, f = len(lens), max(lens), n_fft // 2 + 1
+    rng = np.random.default_rng(67)
+    s = np.zeros((b, t_max, f), np.float32)
+    ph = np.zeros((b, t_max, f, 2), np.float32)
+    for i, t in enumerate(lens):
+        s[i, :t] = rng.standard_normal((t, f)) ** 2
+        ang = rng.uniform(0, 2 * np.pi, (t, f))
+        ph[i, :t, :, 0], ph[i, :t, :, 1] = np.cos(ang), np.sin(ang)
+    plan = voc.GriffinLimPlan(n_fft, hop, n_fft, 80, t_max, b)
+    if plan.persistent_capacity(0) <= 0:
+        plan.close()
+        pytest.skip("no iteration-spanning launches on this device")
+    plan.set_option("single_frame", 0)     # (so small a batch would get a wave per frame otherwise)
+    plan.set_option("group_frames", -1)
+    whole = plan.griffinlim(dev(s), lens, phase0=dev(ph), n_iter=8).clone()
+    assert plan.last_loop_groups() == 1
+    plan.set_option("group_frames", 300)
+    cut = plan.griffinlim(dev(s), lens, phase0=dev(ph), n_iter=8).clone()
+    groups = plan.last_loop_groups()
+    assert groups == 3 and plan.last_loop_launches() == 1
+    plan.status()
+    for i, t in enumerate(lens):
+        n = hop * (t - 1)
+        err = float((cut[i, :n] - whole[i, :n]).norm() / whole[i, :n].norm())
+        assert err < 2e-5, (i, err)
+    # the groups as calls of their own: the same cut of the list by frames (thirds of 864)
+    bounds, acc, total, g = [0], 0, sum(lens), 1
+    for i, t in enumerate(lens):
+        if g < groups and acc + t // 2 > total * g // groups and i > bounds[-1]:
+            bounds.append(i)
+            g += 1
+        acc += t
+    bounds.append(b)
+    assert len(bounds) == groups + 1
+    plan.set_option("group_frames", -1)
+    for b0, b1 in zip(bounds[:-1], bounds[1:]):
+        part = plan.griffinlim(dev(s[b0:b1]), lens[b0:b1], phase0=dev(ph[b0:b1]), n_iter=8)
+        for i in range(b0, b1):
+            n = hop * (lens[i] - 1)
+            assert torch.equal(part[i - b0, :n], cut[i, :n]), (b0, b1, i)
+    plan.close()
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (2048, 256)])
 def test_shard_run_replayed_from_one_graph(voc, n_fft, hop):
     """glv_shard_run enqueues the steps and swaps after the first swap one by one (option
     "shard_graph" 0), replays them from one hipGraph (1), or from a graph with two branches in

@@ -84,6 +84,7 @@ SIGNATURES = {
     "glv_plan_status": (ctypes.c_int, [ctypes.c_void_p]),
     "glv_plan_persistent_capacity": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "glv_plan_last_loop_launches": (ctypes.c_int, [ctypes.c_void_p]),
+    "glv_plan_last_loop_groups": (ctypes.c_int, [ctypes.c_void_p]),
     "glv_shard_last_run_form": (ctypes.c_int, [ctypes.c_void_p]),
     "glv_plan_drawn_phase": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),

@@ -74,6 +74,16 @@ struct glv_plan {
     int single_frame = -1;  // one frame per wave: -1 = when the batch is too small to fill the device
                             // with runs, 0 = never, 1 = always
     bool cur_single = false;    // the run table in place is one run per frame
+    // A batch too large for one iteration-spanning launch is cut into groups of consecutive
+    // utterances, each with a run table of its own that fits such a launch (the tables lie one
+    // after the other in d_runs): [r0, r1) of every group, empty when the batch is one piece.
+    struct RunGroup {
+        int r0, r1;
+    };
+    std::vector<RunGroup> groups;
+    int64_t cur_group_frames = 0;  // the group size the table in place was cut for (0: one piece)
+    int64_t group_frames = 0;      // option: frames per group (0 = automatic, -1 = never cut)
+    int last_loop_groups = 1;
     // All iterations of a call in ONE launch (MODE_ITER_LIN_P / _Z_P) when the call's workgroups
     // are resident together: -1 = off for good (a launch timed out), 0 = off, 1 = on.
     int persistent = 1;         // (2: even when the launch cannot be resident as a whole - a test aid)
@@ -525,7 +535,7 @@ size_t runs_bound(const glv_plan* p, int64_t frames, bool single) {
 // (Re)builds the run table for these lengths and uploads it.  Cached: a call with
 // the lengths of the previous call costs nothing.
 int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_stride, hipStream_t st,
-                 bool single = false, bool deposit = false) {
+                 bool single = false, bool deposit = false, int64_t group_frames = 0, int64_t group_runs = 0) {
     if (!n_frames_host) return fail(GLV_ERR_INVALID, "n_frames_host is null");
     if (batch < 1 || batch > p->max_batch)
         return fail(GLV_ERR_INVALID, "batch %d outside [1, %d]", batch, p->max_batch);
@@ -537,11 +547,47 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
                         frames_stride);
     const bool same = (int)p->cur_nframes.size() == batch && p->cur_frames_stride == frames_stride &&
                       p->cur_fpr == p->frames_per_run && p->cur_target == p->run_target &&
-                      p->cur_single == single && p->cur_deposit == deposit &&
+                      p->cur_single == single && p->cur_deposit == deposit && p->cur_group_frames == group_frames &&
                       memcmp(p->cur_nframes.data(), n_frames_host, sizeof(int) * batch) == 0;
     if (same) return GLV_OK;
     std::vector<RunDesc> runs;
-    if (single) {
+    std::vector<glv_plan::RunGroup> groups;
+    std::vector<unsigned char> flags;
+    if (group_frames > 0) {
+        // groups of consecutive utterances of about group_frames frames each, every one with the
+        // run table a call of those utterances alone would get (at most group_runs runs); the tail
+        // flags follow each group's own workgroups
+        int64_t total = 0;
+        for (int b = 0; b < batch; ++b) total += n_frames_host[b];
+        const int n_groups = (int)std::max<int64_t>(1, (total + group_frames / 2) / group_frames);
+        flags.assign((size_t)batch * p->blocks, 0);
+        int b0 = 0;
+        int64_t seen = 0;
+        for (int g = 0; g < n_groups && b0 < batch; ++g) {
+            // utterances up to this group's share of the frames (the last group takes the rest)
+            const int64_t upto = g + 1 == n_groups ? total : (total * (g + 1)) / n_groups;
+            int b1 = b0;
+            int64_t mine = 0;
+            while (b1 < batch && (b1 == b0 || g + 1 == n_groups || seen + mine + n_frames_host[b1] / 2 <= upto)) {
+                mine += n_frames_host[b1];
+                ++b1;
+            }
+            seen += mine;
+            const int64_t target = std::min<int64_t>(
+                group_runs, pick_run_target(mine, p->n_cus, kWavesPerBlock, p->blocks_per_cu, std::max(1, p->R - 1)));
+            std::vector<RunDesc> part = build_runs_target(n_frames_host + b0, b1 - b0, target, p->R);
+            for (RunDesc& r : part) r.utt += b0;
+            const std::vector<unsigned char> f =
+                build_tail_flags(part, batch, p->blocks, p->R, deposit ? kWavesPerBlock : 0);
+            for (size_t i = (size_t)b0 * p->blocks; i < (size_t)b1 * p->blocks; ++i) flags[i] = f[i];
+            groups.push_back(glv_plan::RunGroup{(int)runs.size(), (int)(runs.size() + part.size())});
+            runs.insert(runs.end(), part.begin(), part.end());
+            b0 = b1;
+        }
+    }
+    if (!groups.empty()) {
+        // (the groups' tables, one after the other)
+    } else if (single) {
         for (int b = 0; b < batch; ++b)
             for (int t = 0; t < n_frames_host[b]; ++t) runs.push_back(RunDesc{b, t, t + 1, n_frames_host[b]});
     } else if (p->frames_per_run > 0) {
@@ -561,7 +607,10 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
         runs = build_runs_target(n_frames_host, batch, target, p->R);
     }
     if (runs.size() > p->max_runs) return fail(GLV_ERR_INVALID, "run table overflow");
-    std::vector<unsigned char> flags = build_tail_flags(runs, batch, p->blocks, p->R, deposit ? kWavesPerBlock : 0);
+    if (groups.size() < 2) {
+        groups.clear();
+        flags = build_tail_flags(runs, batch, p->blocks, p->R, deposit ? kWavesPerBlock : 0);
+    }
     glv_plan::Staging* sg = nullptr;
     int rc = acquire_staging(p, &sg);
     if (rc != GLV_OK) return rc;
@@ -591,6 +640,8 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     p->cur_target = p->run_target;
     p->cur_single = single;
     p->cur_deposit = deposit;
+    p->cur_group_frames = group_frames;
+    p->groups = groups;
     p->n_runs = (int)runs.size();
     return GLV_OK;
 }
@@ -815,6 +866,9 @@ extern "C" int glv_plan_set_option(glv_plan* p, const char* name, int value) {
     } else if (!strcmp(name, "persistent")) {
         if (value < 0 || value > 2) return fail(GLV_ERR_INVALID, "persistent must be 0, 1 or 2");
         if (p->persistent >= 0) p->persistent = value;
+    } else if (!strcmp(name, "group_frames")) {
+        if (value < -1) return fail(GLV_ERR_INVALID, "group_frames is -1 (never cut a batch into groups), 0 (automatic) or a number of frames");
+        p->group_frames = value;
     } else if (!strcmp(name, "halo_loopback")) {
         p->halo_loopback = value != 0;
     } else if (!strcmp(name, "shard_graph")) {
@@ -1201,9 +1255,15 @@ bool persistent_fits(const glv_plan* p, bool lin_runs, bool with_sc, int n_iter,
 }
 
 // all n_iter iterations as ONE launch: progress words cleared, then the kernel
-int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, hipStream_t st, bool single = false) {
-    HIP_TRY(hipMemsetAsync(p->d_progress, 0, (size_t)(1 + p->n_runs) * kProgressStride * sizeof(int), st));
+int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, hipStream_t st, bool single = false,
+                       int run_first = 0, int run_count = -1) {
+    // (runs [run_first, run_first + run_count) of the table: one group of a batch cut into groups)
+    if (run_count < 0) run_count = p->n_runs;
+    HIP_TRY(hipMemsetAsync(p->d_progress, 0, (size_t)(1 + run_count) * kProgressStride * sizeof(int), st));
     IterArgs a = iter_args(p, frames_stride);
+    a.runs = p->d_runs + run_first;
+    a.n_runs = run_count;
+    const size_t grid = (size_t)(run_count + kWavesPerBlock - 1) / kWavesPerBlock;
     a.cmom = cmom;
     a.n_iter = n_iter;
     if (single) {
@@ -1212,7 +1272,7 @@ int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, h
         a.status = p->d_progress;
         a.progress = p->d_progress + kProgressStride;
         a.host_status = p->h_status_dev;
-        HIP_TRY(p->launch_engine(MODE_ITER1_P, false, a, engine_grid(p), st));
+        HIP_TRY(p->launch_engine(MODE_ITER1_P, false, a, grid, st));
         return GLV_OK;
     }
     for (int g = 0; g < 3; ++g) {
@@ -1226,7 +1286,7 @@ int enqueue_persistent(glv_plan* p, int frames_stride, int n_iter, float cmom, h
     a.progress = p->d_progress + kProgressStride;
     a.host_status = p->h_status_dev;
     const bool all_bins = p->cur_nzh == 4 * p->A;
-    HIP_TRY(p->launch_engine(all_bins ? MODE_ITER_LIN_P : MODE_ITER_LIN_Z_P, false, a, engine_grid(p), st));
+    HIP_TRY(p->launch_engine(all_bins ? MODE_ITER_LIN_P : MODE_ITER_LIN_Z_P, false, a, grid, st));
     return GLV_OK;
 }
 
@@ -1260,8 +1320,33 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     // all of them can (n_fft 1024, the iteration that keeps no spectrum, no convergence curve).
     const bool deposit = p->deposit && p->A == 1 && kWavesPerBlock > 1 && !single && three_generations(p) &&
                          !p->recompute && !(sc_curve_dev != nullptr && n_iter > 0);
-    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single, deposit);
+    // a wait of an earlier iteration-spanning launch ran out: that call's results were void
+    // (glv_plan_status reports it); from now on the loop is launched one iteration at a time
+    if (p->persistent > 0 && p->h_status && *(volatile int*)p->h_status != 0) p->persistent = -1;
+    const bool with_sc = sc_curve_dev != nullptr && n_iter > 0;
+    // The time-domain-momentum iteration keeps the magnitudes in pair order; with magnitudes that
+    // come from this plan's inverse basis it also knows which bins are zero for good.
+    const bool lin_runs = !single && three_generations(p) && !p->recompute;
+    p->cur_nzh = lin_runs ? pair_nzh(p, src.mel_db_dev != nullptr) : 0;
+    // A batch of more runs than one iteration-spanning launch holds is cut into groups of
+    // consecutive utterances that each get such a launch: a group of about 18 frames per wave
+    // slot is where those launches do best (64 / 128 / 256 utterances of 430 frames in one launch:
+    // 147.6 / 156.0 / 147.5 k audio-s/s), and a launch per iteration over everything does worse
+    // than any of them (512 utterances: 139.7 k).  n_fft 2048, 865 frames: 64 / 128 utterances in
+    // one launch 72.0 / 73.6 k, 128 as two groups of 64 72.7 k - there 54 frames per slot.  Not with
+    // a fixed run length (option frames_per_run; 4096 utterances in runs of 32 frames: 138.1 k in 19
+    // groups against 139.8 k in one piece), whose tables must not depend on who shares the call.
+    int64_t group_frames = 0, group_runs = 0;
+    if (plain && lin_runs && !with_sc && n_iter > 0 && p->persistent > 0 && p->group_frames >= 0 &&
+        p->frames_per_run == 0 && p->run_target == 0 && (p->A != 1 || deposit)) {
+        const int variant = p->cur_nzh == 4 * p->A ? 0 : 1;
+        group_runs = (int64_t)p->persist_capacity[variant] * kWavesPerBlock;
+        group_frames = p->group_frames > 0 ? p->group_frames : (p->A == 1 ? 18 : 54) * group_runs;
+        if (group_runs <= 0 || (total_frames + group_frames / 2) / group_frames < 2) group_frames = 0;
+    }
+    int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single, deposit, group_frames, group_runs);
     if (rc != GLV_OK) return rc;
+    const bool grouped = !p->groups.empty();
     if (single) {
         p->parts_utt_stride = (int64_t)(frames_stride + p->R) * p->hop;
         p->parts_stride = (int64_t)batch * p->parts_utt_stride;
@@ -1275,15 +1360,10 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (y_stride < (int64_t)p->hop * (max_t - 1))
         return fail(GLV_ERR_INVALID, "y_stride %lld shorter than hop*(n_frames-1) = %lld",
                     (long long)y_stride, (long long)p->hop * (max_t - 1));
-    const bool with_sc = sc_curve_dev != nullptr && n_iter > 0;
     if (with_sc) {
         rc = ensure_sc(p, (size_t)n_iter * p->n_runs * 2, st);
         if (rc != GLV_OK) return rc;
     }
-    // The time-domain-momentum iteration keeps the magnitudes in pair order; with magnitudes that
-    // come from this plan's inverse basis it also knows which bins are zero for good.
-    const bool lin_runs = !single && three_generations(p) && !p->recompute;
-    p->cur_nzh = lin_runs ? pair_nzh(p, src.mel_db_dev != nullptr) : 0;
     ElemArgs ea = elem_args(p, batch, frames_stride);
     ea.L.s_pair_nzh = p->cur_nzh;
     const float inv_n = 1.0f / (float)p->n_fft;
@@ -1312,6 +1392,16 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     if (single) {
         set_parts_io(p, a, 1, 0);
         HIP_TRY(p->launch_engine(MODE_ISTFT1, false, a, engine_grid(p), st));
+    } else if (grouped) {
+        // (every group's runs form workgroups of their own: one launch per group)
+        set_io(p, a, 1, 0);
+        for (const glv_plan::RunGroup& g : p->groups) {
+            a.runs = p->d_runs + g.r0;
+            a.n_runs = g.r1 - g.r0;
+            HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, (size_t)(a.n_runs + kWavesPerBlock - 1) / kWavesPerBlock, st));
+        }
+        a.runs = p->d_runs;
+        a.n_runs = p->n_runs;
     } else {
         set_io(p, a, 1, 0);
         HIP_TRY(p->launch_engine(MODE_ISTFT, false, a, engine_grid(p), st));
@@ -1324,11 +1414,17 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
 
     const float cmom = momentum / (1.0f + momentum);
     if (p->timing) HIP_TRY(hipEventRecord(p->ev0, st));
-    // a wait of an earlier iteration-spanning launch ran out: that call's results were void
-    // (glv_plan_status reports it); from now on the loop is launched one iteration at a time
-    if (p->persistent > 0 && p->h_status && *(volatile int*)p->h_status != 0) p->persistent = -1;
     p->last_loop_launches = n_iter;
-    if (n_iter > 0 && persistent_fits(p, lin_runs, with_sc, n_iter, single)) {
+    p->last_loop_groups = 1;
+    if (grouped) {
+        // one iteration-spanning launch per group, one after the other
+        for (const glv_plan::RunGroup& g : p->groups) {
+            rc = enqueue_persistent(p, frames_stride, n_iter, cmom, st, false, g.r0, g.r1 - g.r0);
+            if (rc != GLV_OK) return rc;
+        }
+        p->last_loop_launches = 1;
+        p->last_loop_groups = (int)p->groups.size();
+    } else if (n_iter > 0 && persistent_fits(p, lin_runs, with_sc, n_iter, single)) {
         rc = enqueue_persistent(p, frames_stride, n_iter, cmom, st, single);
         if (rc != GLV_OK) return rc;
         p->last_loop_launches = 1;
@@ -1519,6 +1615,7 @@ extern "C" int glv_shard_begin(glv_plan* p, const float* S_dev, const float* pha
     HIP_TRY(hipMemcpyAsync(p->d_nframes, sg->ints, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(release_staging(sg, st));
     p->cur_nframes.clear();  // the batch path must rebuild its own tables afterwards
+    p->groups.clear();
     p->cur_deposit = deposit;
     p->n_runs = (int)runs.size();
     p->shard_t0 = t0;
@@ -1949,6 +2046,7 @@ extern "C" int glv_shard_run(glv_plan* p, int n_iter, float momentum, void* stre
 }
 
 extern "C" int glv_shard_last_run_form(const glv_plan* p) { return p ? p->shard_last_form : 0; }
+extern "C" int glv_plan_last_loop_groups(const glv_plan* p) { return p ? p->last_loop_groups : 0; }
 
 namespace {
 

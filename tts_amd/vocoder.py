@@ -186,6 +186,10 @@ class GriffinLimPlan:
         """Kernel launches the iteration loop of the last call took (1: all iterations in one)."""
         return int(self.lib.glv_plan_last_loop_launches(self._handle))
 
+    def last_loop_groups(self):
+        """Groups of utterances the last call's loop was cut into (each its own launch or launches)."""
+        return int(self.lib.glv_plan_last_loop_groups(self._handle))
+
     def last_loop_ms(self):
         ms = ctypes.c_float()
         _lib.check(self.lib.glv_plan_last_loop_ms(self._handle, ctypes.byref(ms)))
