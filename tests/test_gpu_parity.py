@@ -1051,7 +1051,7 @@ def test_large_batch_cut_into_groups_of_utterances(voc, n_fft, hop):
     utterances alone gets (option "group_frames" sets the size, here small enough to cut a small
     batch).  Every group's rows must therefore equal, bit for bit, what a call of just that group
     returns, and the whole must agree with the uncut batch (other run boundaries: a few sums
-    associate differently) to rounding."""
+    associate differently) to rounding - bit for bit when the run length is fixed."""
     lens = [90, 64, 120, 33, 77, 101, 58, 96, 45, 110, 70]
     b, t_max, f = len(lens), max(lens), n_fft // 2 + 1
     rng = np.random.default_rng(67)
@@ -1093,6 +1093,15 @@ def test_large_batch_cut_into_groups_of_utterances(voc, n_fft, hop):
         for i in range(b0, b1):
             n = hop * (lens[i] - 1)
             assert torch.equal(part[i - b0, :n], cut[i, :n]), (b0, b1, i)
+    # with a fixed run length an utterance's runs do not depend on its group: cut or not, same bits
+    plan.set_option("frames_per_run", 2 * (n_fft // hop))
+    uncut = plan.griffinlim(dev(s), lens, phase0=dev(ph), n_iter=8).clone()
+    assert plan.last_loop_groups() == 1
+    plan.set_option("group_frames", 300)
+    cut = plan.griffinlim(dev(s), lens, phase0=dev(ph), n_iter=8)
+    assert plan.last_loop_groups() == 3
+    assert torch.equal(cut, uncut)
+    plan.status()
     plan.close()
 
 

@@ -575,7 +575,15 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
             seen += mine;
             const int64_t target = std::min<int64_t>(
                 group_runs, pick_run_target(mine, p->n_cus, kWavesPerBlock, p->blocks_per_cu, std::max(1, p->R - 1)));
-            std::vector<RunDesc> part = build_runs_target(n_frames_host + b0, b1 - b0, target, p->R);
+            std::vector<RunDesc> part = p->frames_per_run > 0
+                                            ? build_runs(n_frames_host + b0, b1 - b0, p->frames_per_run, p->R)
+                                            : build_runs_target(n_frames_host + b0, b1 - b0, target, p->R);
+            if ((int64_t)part.size() > group_runs) {
+                // (a fixed run length that gives a group more runs than a launch holds: one piece)
+                groups.clear();
+                runs.clear();
+                break;
+            }
             for (RunDesc& r : part) r.utt += b0;
             const std::vector<unsigned char> f =
                 build_tail_flags(part, batch, p->blocks, p->R, deposit ? kWavesPerBlock : 0);
@@ -1333,15 +1341,19 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     // slot is where those launches do best (64 / 128 / 256 utterances of 430 frames in one launch:
     // 147.6 / 156.0 / 147.5 k audio-s/s), and a launch per iteration over everything does worse
     // than any of them (512 utterances: 139.7 k).  n_fft 2048, 865 frames: 64 / 128 utterances in
-    // one launch 72.0 / 73.6 k, 128 as two groups of 64 72.7 k - there 54 frames per slot.  Not with
-    // a fixed run length (option frames_per_run; 4096 utterances in runs of 32 frames: 138.1 k in 19
-    // groups against 139.8 k in one piece), whose tables must not depend on who shares the call.
+    // one launch 72.0 / 73.6 k, 128 as two groups of 64 72.7 k - there 54 frames per slot.  With a
+    // fixed run length (option frames_per_run: an utterance's runs, and with them its bits, then do
+    // not depend on who shares the call or the group) a group is as many utterances as nearly fill
+    // a launch; 4096 utterances of N(560, 190) frames in runs of 32 / 24 / 18 / 14 frames: 138.6 /
+    // 145.4 / 152.4 / 149.8 k in groups against 140.4 / 139.6 / 137.3 / 133.4 k in one piece.
     int64_t group_frames = 0, group_runs = 0;
     if (plain && lin_runs && !with_sc && n_iter > 0 && p->persistent > 0 && p->group_frames >= 0 &&
-        p->frames_per_run == 0 && p->run_target == 0 && (p->A != 1 || deposit)) {
+        p->run_target == 0 && (p->A != 1 || deposit)) {
         const int variant = p->cur_nzh == 4 * p->A ? 0 : 1;
         group_runs = (int64_t)p->persist_capacity[variant] * kWavesPerBlock;
-        group_frames = p->group_frames > 0 ? p->group_frames : (p->A == 1 ? 18 : 54) * group_runs;
+        group_frames = p->group_frames > 0    ? p->group_frames
+                       : p->frames_per_run > 0 ? (int64_t)p->frames_per_run * group_runs * 15 / 16
+                                               : (p->A == 1 ? 18 : 54) * group_runs;
         if (group_runs <= 0 || (total_frames + group_frames / 2) / group_frames < 2) group_frames = 0;
     }
     int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single, deposit, group_frames, group_runs);
