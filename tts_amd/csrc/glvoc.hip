@@ -554,12 +554,13 @@ int prepare_runs(glv_plan* p, const int* n_frames_host, int batch, int frames_st
     std::vector<glv_plan::RunGroup> groups;
     std::vector<unsigned char> flags;
     if (group_frames > 0) {
-        // groups of consecutive utterances of about group_frames frames each, every one with the
+        // groups of consecutive utterances, as few and as even as keeps each at about group_frames
+        // frames or fewer, every one with the
         // run table a call of those utterances alone would get (at most group_runs runs); the tail
         // flags follow each group's own workgroups
         int64_t total = 0;
         for (int b = 0; b < batch; ++b) total += n_frames_host[b];
-        const int n_groups = (int)std::max<int64_t>(1, (total + group_frames / 2) / group_frames);
+        const int n_groups = (int)std::max<int64_t>(1, (total + group_frames - 1) / group_frames);
         flags.assign((size_t)batch * p->blocks, 0);
         int b0 = 0;
         int64_t seen = 0;
@@ -1337,10 +1338,12 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
     const bool lin_runs = !single && three_generations(p) && !p->recompute;
     p->cur_nzh = lin_runs ? pair_nzh(p, src.mel_db_dev != nullptr) : 0;
     // A batch of more runs than one iteration-spanning launch holds is cut into groups of
-    // consecutive utterances that each get such a launch: a group of about 18 frames per wave
-    // slot is where those launches do best (64 / 128 / 256 utterances of 430 frames in one launch:
-    // 147.6 / 156.0 / 147.5 k audio-s/s), and a launch per iteration over everything does worse
-    // than any of them (512 utterances: 139.7 k).  n_fft 2048, 865 frames: 64 / 128 utterances in
+    // consecutive utterances that each get such a launch - and so is one that would fit a single
+    // launch but with more than 19 frames per wave slot: 1024 utterances of 430 frames in groups of
+    // 10 / 14 / 16 / 18 / 20 / 24 frames per slot give 148.8 / 153.7 / 156.2 / 154.7 / 149.5 / 146.7 k
+    // audio-s/s (beyond 19 a group's working set per iteration no longer fits the 256 MB of
+    // memory-side cache), and a launch per iteration over everything does worse than any of them
+    // (512 utterances: 139.7 k).  n_fft 2048, 865 frames: 64 / 128 utterances in
     // one launch 72.0 / 73.6 k, 128 as two groups of 64 72.7 k - there 54 frames per slot.  With a
     // fixed run length (option frames_per_run: an utterance's runs, and with them its bits, then do
     // not depend on who shares the call or the group) a group is as many utterances as nearly fill
@@ -1353,8 +1356,12 @@ int griffinlim_impl(glv_plan* p, const MagnitudeSource& src, const float* phase0
         group_runs = (int64_t)p->persist_capacity[variant] * kWavesPerBlock;
         group_frames = p->group_frames > 0    ? p->group_frames
                        : p->frames_per_run > 0 ? (int64_t)p->frames_per_run * group_runs * 15 / 16
-                                               : (p->A == 1 ? 18 : 54) * group_runs;
-        if (group_runs <= 0 || (total_frames + group_frames / 2) / group_frames < 2) group_frames = 0;
+                                               : (p->A == 1 ? 19 : 60) * group_runs;
+        // (up to an eighth over the limit two groups of half the size would be the slower choice:
+        // 144 utterances 150.5 k in one piece against 148.8 k in two groups, 160: 148.3 against 151.1 k)
+        if (group_runs <= 0 || (p->group_frames == 0 && p->frames_per_run == 0 && total_frames * 8 <= group_frames * 9) ||
+            (total_frames + group_frames - 1) / group_frames < 2)
+            group_frames = 0;
     }
     int rc = prepare_runs(p, n_frames_host, batch, frames_stride, st, single, deposit, group_frames, group_runs);
     if (rc != GLV_OK) return rc;
