@@ -348,6 +348,7 @@ struct Engine {
         share_next = nullptr;
         deposit_out = nullptr;
         deposit_in = nullptr;
+        ring_prev = nullptr;
         heads_shared = false;
         tails_shared = false;
         tab.twA = tables;
@@ -436,6 +437,13 @@ struct Engine {
     // tail sums from memory within the same launch, so those stores are written through (st_shared)
     bool heads_shared = false;
     bool tails_shared = false;
+    // Iteration-spanning kernels, n_fft 1024: a run that completes its last R-1 blocks itself
+    // (deposit_in) has, at the end of an iteration, everything the NEXT iteration's hand-over
+    // between it and its successor consists of - the complete blocks of this iteration and of the
+    // one before.  It leaves y_k - c y_{k-1} of those blocks in the LDS slot both runs read
+    // (share_next; what the successor's preload would have made from memory) and keeps the
+    // normalised blocks of this iteration in ring_prev for the next time.
+    cf* ring_prev = nullptr;
     GLV_HD bool from_next(int j) const { return share_next != nullptr && j >= run.t_end; }
     GLV_HD bool block_valid(int j) const { return j >= R / 2 && j < R / 2 + run.n_frames - 1 + block_extra; }
     GLV_HD bool block_has_tail(const IterArgs& a, int j) const {
@@ -686,6 +694,43 @@ struct Engine {
         }
         combine_rows<false, 0, (R - 1) * HB>(c);
         publish_preload(slot);
+    }
+    // the window-sum-square rows of blocks t_end .. t_end+R-2, requested after the last frame into
+    // the fetch buffers (their way from the cache passes under flush_tails)
+    // (one fetch buffer per block, those the frame loop uses first)
+    static constexpr bool kRingShape = A == 1 && R - 1 <= 6;
+    GLV_HD void fetch_ring_rows(const IterArgs& a) {
+        cf* dst[6] = {blk_n.main, blk_n.w, blkp_n.main, blk_n.tail, blkp_n.tail, blkp_n.w};
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) {
+            const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, run.t_end + q);
+#pragma unroll
+            for (int i = 0; i < HB; ++i) load_row(pw, i, dst[q]);
+        }
+    }
+    // after flush_tails of a run with deposit_in (acc holds the complete sums of blocks t_end ..):
+    // normalise them, combine with the blocks of the iteration before (`first`: those are what
+    // the slot still holds from the successor's one preload from memory), leave the result in the
+    // slot and the normalised blocks in ring_prev.  The same operations in the same order as
+    // load_block + combine_rows of a preload from memory.
+    GLV_HD void ring_hand_over(const IterArgs& a, cf* slot, bool first) {
+        static_assert(A == 1, "only the n_fft 1024 kernels share boundary blocks");
+        const cf* wrow[6] = {blk_n.main, blk_n.w, blkp_n.main, blk_n.tail, blkp_n.tail, blkp_n.w};
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int row = q * HB + i, at = row * (ROW / 2) + lane;
+                const cf cn = cf{acc[row].x * wrow[q][i].x, acc[row].y * wrow[q][i].y};
+                const cf pn = first ? slot[at] : ring_prev[at];
+                ring_prev[at] = cn;
+                slot[at] = cf{fmaf(-a.cmom, pn.x, cn.x), fmaf(-a.cmom, pn.y, cn.y)};
+            }
+    }
+    // a run whose predecessor handed over through the slot: the window's first R-1 blocks
+    GLV_HD void take_ring_preload(const cf* mine) {
+#pragma unroll
+        for (int row = 0; row < (R - 1) * HB; ++row) raw[row] = mine[row * (ROW / 2) + lane];
     }
     // block q of the next run's preload = this frame's newest block (the fetch delivered zeros)
     GLV_HD void take_shared(int q) {

@@ -231,7 +231,8 @@ constexpr size_t engine_lds_bytes() {
     using G = Geo<A>;
     return (size_t)(table_span<A, HB>() + kWavesPerBlock * G::XBUF) * sizeof(cf) +
            (A == 1 ? (size_t)(kWavesPerBlock + 1) * Engine<A, HB>::kShareFloats * sizeof(float) +
-                         4 * kWavesPerBlock * sizeof(int)  // flag words of the iteration-spanning kernels
+                         4 * kWavesPerBlock * sizeof(int) +  // flag words of the iteration-spanning kernels
+                         Engine<A, HB>::kShareFloats * sizeof(float)  // ... and one set of boundary blocks
                    : 0);
 }
 

@@ -167,7 +167,16 @@ __device__ __forceinline__ void enter_iteration(IterArgs& a, EngT& e, int& g_cur
 #ifndef GLV_PERSIST_TWR
 #define GLV_PERSIST_TWR 1
 #endif
-// second launch bound = waves per SIMD the register allocator must leave room for
+// 1: iteration-spanning kernels, n_fft 1024: a run that completes its boundary with the next run of
+// its workgroup also makes that boundary's hand-over for the next iteration, in LDS
+// (Engine::ring_hand_over): after the first iteration no run loads blocks that a wave of its own
+// workgroup wrote, and the barrier after the preload goes
+#ifndef GLV_PERSIST_RING
+#define GLV_PERSIST_RING 1
+#endif
+// second launch bound = waves per SIMD the register allocator must leave room for (the
+// iteration-spanning run kernels of n_fft 1024 are held to three: they sit within a register or two
+// of that limit, and a launch that holds a third fewer workgroups does not fit the usual batch)
 #ifndef GLV_MIN_WAVES_A1
 #define GLV_MIN_WAVES_A1 2
 #endif
@@ -189,7 +198,7 @@ __device__ unsigned long long glv_wave_times[20 * 16384];
 #endif
 
 template <int A, int HB, int MODE, bool SC>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? GLV_MIN_WAVES_A1 : GLV_MIN_WAVES_A2)) void
+__global__ __launch_bounds__(64 * kWavesPerBlock, (A == 1 ? ((MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P) ? 3 : GLV_MIN_WAVES_A1) : GLV_MIN_WAVES_A2)) void
 gl_engine_kernel(IterArgs a) {
     using G = Geo<A>;
     // Kernels that can complete run boundaries on the producer's side.  They keep every table in
@@ -268,6 +277,7 @@ gl_engine_kernel(IterArgs a) {
     // (n_fft 2048 too: there the waves of a workgroup exchange both halves of their boundary blocks
     // through this CU's own plain stores)
     constexpr bool kEndBarrier = kPersist && !kPersist1 && !kFlags;
+    constexpr bool kRing = kPersist && !kPersist1 && Eng::kRingShape && GLV_PERSIST_RING && !GLV_PERSIST_FLAGS && GLV_PERSIST_TWR == 1;
     const bool live = ri < a.n_runs;
     const bool deposit = kCanDeposit && a.deposit != 0;  // the same in every wave of the launch
     const int n_outer = kPersist ? a.n_iter : 1;
@@ -289,7 +299,7 @@ gl_engine_kernel(IterArgs a) {
     if (!live) {
         // a wave without a run only keeps the workgroup's barriers company
         for (int k = 0; k < n_outer; ++k) {
-            if (kShare || (deposit && k == 0)) __syncthreads();  // after the set-up
+            if ((kShare && (!kRing || k == 0)) || (deposit && k == 0)) __syncthreads();  // after the set-up
             if (kFlags) break;                                   // ... the only barrier there is
             if (deposit) __syncthreads();                        // before the tails are completed
             if (kEndBarrier) __syncthreads();
@@ -353,6 +363,15 @@ gl_engine_kernel(IterArgs a) {
         // the blocks after the run's last frame always come from LDS: the next run's published
         // preload, or this run's own (preload_next); slot wave + 1 either way
         if (A == 1) e.share_next = shared_blocks + (wave + 1) * (Eng::kShareFloats / 2);
+        if constexpr (kRing) {
+            // the blocks of the iteration before, one set per boundary inside the workgroup: in the
+            // slot no run publishes to (wave 0 has no predecessor here), over the two twiddle tables
+            // (every wave holds them in registers) and behind the flag words
+            if (e.deposit_in != nullptr)
+                e.ring_prev = wave == 0   ? shared_blocks
+                              : wave == 1 ? tables
+                                          : shared_blocks + (kWavesPerBlock + 1) * (Eng::kShareFloats / 2) + 2 * kWavesPerBlock;
+        }
         enter_iteration<kNzh>(a, e, g_cur, 0);
     }
     // (not a loop at all unless the kernel spans iterations: inside a loop the compiler hoists every
@@ -471,10 +490,15 @@ gl_engine_kernel(IterArgs a) {
                 e.share_next = keep;
             }
             GLV_SCHED_FENCE();
-            e.template preload_lin<SC>(a);
-            if (e.deposit_out != nullptr) {
-                e.publish_preload(mine);
-                if (kFlags) lds_raise(lflag + wave, k + 1, lane);
+            if (kRing && k > 0 && e.deposit_out != nullptr) {
+                // the run before this one left these blocks in the slot at the end of its iteration
+                e.take_ring_preload(mine);
+            } else {
+                e.template preload_lin<SC>(a);
+                if (e.deposit_out != nullptr) {
+                    e.publish_preload(mine);
+                    if (kFlags) lds_raise(lflag + wave, k + 1, lane);
+                }
             }
             GLV_SCHED_FENCE();
         } else if (live) {
@@ -482,7 +506,7 @@ gl_engine_kernel(IterArgs a) {
             e.publish_preload(mine);
         }
         // (with flags: once, so that every wave holds its tables in registers before the first deposit)
-        if (!kFlags || k == 0) __syncthreads();
+        if ((!kFlags && !kRing) || k == 0) __syncthreads();
         // the next run, if it continues this utterance inside this workgroup
         if (!kPersist && wave + 1 < kWavesPerBlock && ri + 1 < a.n_runs && !a.raw_in) {
             const int next_utt = __builtin_amdgcn_readfirstlane(a.runs[ri + 1].utt);
@@ -638,7 +662,13 @@ gl_engine_kernel(IterArgs a) {
     } else {
         if (deposit) __syncthreads();  // the deposits this wave's tails need were made frames ago; now they are visible
     }
+    if constexpr (kRing) {
+        if (e.ring_prev != nullptr) e.fetch_ring_rows(a);
+    }
     if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
+    if constexpr (kRing) {
+        if (e.ring_prev != nullptr) e.ring_hand_over(a, const_cast<cf*>(e.share_next), k == 0);
+    }
     if constexpr (kPersist1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
