@@ -1,15 +1,13 @@
 #!/bin/bash
-# Runs on the GPU box: launch time of the iteration kernel against the number of runs the
-# automatic run table aims at (0 = the device's wave slots), for the batch sizes in $BATCHES.
+# launch time of the iteration kernel against the run count, small batches (runs on the GPU box)
+#   scripts/sweep_target.sh "<batches>" "<targets>"
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-for b in ${BATCHES:-8 16 32 64}; do
-  for t in ${TARGETS:-0 768 1024 1536 2048 2560 2816 3072}; do
-    timeout -k 10 100 python bench.py --no-cpu --batch $b --single-frame 0 --run-target $t ${EXTRA:-} > /tmp/tg.json 2>/tmp/tg.err || { echo "target $t failed"; tail -3 /tmp/tg.err; exit 1; }
-    python - $b $t <<'PY'
-import json, sys
-d = json.loads(open("/tmp/tg.json").read().strip().splitlines()[-1])
-print(f"batch {sys.argv[1]:>3s} run_target {sys.argv[2]:>5s}: {d['roofline']['kernel_ms_per_launch']*1e3:7.2f} us/launch  {d['value']:10.1f} audio-s/s")
-PY
+for b in $1; do
+  for t in $2; do
+    timeout -k 10 100 python bench.py --no-cpu --no-secondary --batch $b --run-target $t --steps 20 --warmup 8 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(f\"batch {sys.argv[1]:>3s} run_target {sys.argv[2]:>5s}: {d['roofline']['kernel_ms_per_iteration']*1e3:7.2f} us/iteration  {d['value']:10.1f} audio-s/s\")" $b $t || exit 1
   done
 done
