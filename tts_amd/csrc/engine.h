@@ -341,6 +341,12 @@ struct Engine {
             load_window_lds(w);
         }
     }
+    // what the loads of the iteration state need (init sets it again, with the rest)
+    GLV_HD void init_run(const IterArgs& a, int lane_, const RunDesc& r) {
+        lane = lane_;
+        run = r;
+        block_extra = a.raw_in ? 1 : 0;
+    }
     GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
         lane = lane_;
         run = r;
@@ -1199,6 +1205,65 @@ struct Engine {
             }
         }
     }
+    // One block of the signal, summed from the partial-sum buffers and normalised exactly as
+    // load_frame_from_parts does it (the value does not depend on which frame asks for it).
+    GLV_HD void sum_block_from_parts(const IterArgs& a, int j, cf (&out)[HV]) const {
+        const int64_t utt_off = (int64_t)run.utt * a.y_utt_stride;
+        const bool valid = block_valid(j);
+        const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, j);
+        cf sum[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) sum[k] = cf{0.f, 0.f};
+#pragma unroll
+        for (int d = R - 1; d >= 0; --d) {
+            const int tc = j - d;
+            const bool ok = valid && tc >= 0 && tc < run.n_frames;
+            const float* p = ok ? a.part_in + (int64_t)(tc & (R - 1)) * a.part_stride + utt_off + (int64_t)j * H : a.zeros;
+            cf part[HV];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) load_row(p, i, part);
+#pragma unroll
+            for (int k = 0; k < HV; ++k) sum[k] = sum[k] + part[k];
+        }
+        cf w[HV];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) load_row(pw, i, w);
+#pragma unroll
+        for (int k = 0; k < HV; ++k) out[k] = cf{sum[k].x * w[k].x, sum[k].y * w[k].y};
+    }
+    // The W consecutive frames t0 .. t0+W-1 of one utterance held by the W waves of a workgroup
+    // need the R+W-1 blocks t0 .. t0+R+W-2 between them: wave `wave` sums every W-th of those
+    // (sum_block_from_parts) into `area` ([block][HV][64] in LDS).  After a workgroup barrier
+    // take_frame_from_area gives every wave its R blocks: R+W-1 blocks summed per workgroup
+    // instead of W x R, the same values.
+    template <int W>
+    GLV_HD void sum_blocks_for_workgroup(const IterArgs& a, int t0, int wave, cf* area) const {
+        constexpr int NB = R + W - 1;
+        cf out[(NB + W - 1) / W][HV];
+#pragma unroll
+        for (int m = 0; m < (NB + W - 1) / W; ++m) {
+            const int b = wave + W * m;
+            // (a wave without an m-th block sums the last block once more, and does not store it)
+            sum_block_from_parts(a, t0 + (b < NB ? b : NB - 1), out[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < (NB + W - 1) / W; ++m) {
+            const int b = wave + W * m;
+            if (b < NB) {
+#pragma unroll
+                for (int k = 0; k < HV; ++k) area[(b * HV + k) * 64 + lane] = out[m][k];
+            }
+        }
+    }
+    GLV_HD void take_frame_from_area(int t, int t0, const cf* area) {
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < A; ++s2)
+#pragma unroll
+                for (int i = 0; i < HB; ++i)
+                    raw[q * HB + i + 8 * s2] = area[((t - t0 + q) * HV + i + HB * s2) * 64 + lane];
+    }
     // the sums of block q have to be in their registers here (and no memory operation moves across)
     GLV_HD void pin_block(int q) {
 #pragma unroll
@@ -1210,9 +1275,10 @@ struct Engine {
             }
     }
     // phase 0 of a single-frame wave: the whole window is fetched, nothing slides
-    template <bool WITH_SPEC>
+    // (FROM_AREA: the frame's blocks are in `raw` already, see sum_blocks_for_workgroup)
+    template <bool WITH_SPEC, bool FROM_AREA = false>
     GLV_HD void ph0_single(const IterArgs& a, int t, cf* w) {
-        load_frame_from_parts(a, t);
+        if (!FROM_AREA) load_frame_from_parts(a, t);
         // the previous spectrum and the magnitudes are not needed before phase 3: their latency
         // hides behind the forward transform
         if (WITH_SPEC) prefetch_spec(a, t);

@@ -167,6 +167,11 @@ __device__ __forceinline__ void enter_iteration(IterArgs& a, EngT& e, int& g_cur
 #ifndef GLV_PERSIST_TWR
 #define GLV_PERSIST_TWR 1
 #endif
+// 1: one frame per wave: the blocks the four frames of a workgroup need are summed once per
+// workgroup (Engine::sum_blocks_for_workgroup)
+#ifndef GLV_COOP_PARTS
+#define GLV_COOP_PARTS 1
+#endif
 // 1: iteration-spanning kernels, n_fft 1024: a run that completes its boundary with the next run of
 // its workgroup also makes that boundary's hand-over for the next iteration, in LDS
 // (Engine::ring_hand_over): after the first iteration no run loads blocks that a wave of its own
@@ -232,6 +237,32 @@ gl_engine_kernel(IterArgs a) {
     bool stamp_on = !(MODE == MODE_ITER_LIN_P || MODE == MODE_ITER_LIN_Z_P);
 #endif
     GLV_STAMP(0)
+    // One frame per wave: a workgroup whose waves hold consecutive frames of one utterance sums
+    // every block those frames need ONCE (R + 3 blocks instead of 4 x R, each from its R
+    // partial-sum buffers) into the exchange buffers, which the transforms do not use yet - and
+    // asks for them first thing, so that their way from memory passes under the staging of the
+    // tables (the barrier behind the staging is also the one behind these sums).
+    bool coop = false;
+    int t_first = 0;
+    Eng e;
+    if constexpr (MODE == MODE_ITER1 && GLV_COOP_PARTS) {
+        const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), first = (int)blockIdx.x * kWavesPerBlock;
+        if (first + kWavesPerBlock <= a.n_runs) {
+            const int u0 = __builtin_amdgcn_readfirstlane(a.runs[first].utt);
+            const int u3 = __builtin_amdgcn_readfirstlane(a.runs[first + kWavesPerBlock - 1].utt);
+            t_first = __builtin_amdgcn_readfirstlane(a.runs[first].t_begin);
+            coop = u0 == u3;
+        }
+        if (coop) {
+            RunDesc r0 = a.runs[first + wave0];
+            r0.utt = __builtin_amdgcn_readfirstlane(r0.utt);
+            r0.t_begin = __builtin_amdgcn_readfirstlane(r0.t_begin);
+            r0.t_end = __builtin_amdgcn_readfirstlane(r0.t_end);
+            r0.n_frames = __builtin_amdgcn_readfirstlane(r0.n_frames);
+            e.init_run(a, threadIdx.x & 63, r0);
+            e.template sum_blocks_for_workgroup<kWavesPerBlock>(a, t_first, wave0, tables + kSpan);
+        }
+    }
     {
         // stage the tables: all of a thread's loads are issued before the first is stored, so
         // the block pays one memory latency, not one per round
@@ -314,7 +345,6 @@ gl_engine_kernel(IterArgs a) {
     rd.t_begin = __builtin_amdgcn_readfirstlane(rd.t_begin);
     rd.t_end = __builtin_amdgcn_readfirstlane(rd.t_end);
     rd.n_frames = __builtin_amdgcn_readfirstlane(rd.n_frames);
-    Eng e;
     e.init(a, tables, lane, rd);
     if (kCanDeposit && deposit) {
         // wave w > 0 deposits for wave w - 1 when its run continues that wave's utterance
@@ -440,7 +470,14 @@ gl_engine_kernel(IterArgs a) {
         // one frame per wave: the run is the frame
         const int t = e.run.t_begin;
         if (MODE == MODE_ITER1 || kPersist1) {
-            e.template ph0_single<true>(a, t, xb);
+            if (coop) {
+                // (summed before the tables were staged, see the kernel's start)
+                e.take_frame_from_area(t, t_first, tables + kSpan);
+                __syncthreads();  // every wave has its blocks: the buffers are the transforms' again
+                e.template ph0_single<true, true>(a, t, xb);
+            } else {
+                e.template ph0_single<true>(a, t, xb);
+            }
             GLV_STAMP(4)
             wave_sync();
             e.ph1_read(xb);
