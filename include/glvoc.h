@@ -308,8 +308,9 @@ int glv_shard_exchange(glv_plan* plan, void* stream);
 /* glv_shard_exchange, then n_iter times { glv_shard_step; glv_shard_exchange }: the whole loop
  * after glv_shard_begin enqueued by one call. */
 int glv_shard_run(glv_plan* plan, int n_iter, float momentum, void* stream);
-/* How the last glv_shard_run enqueued its steps and swaps (option "shard_graph" asks for a form,
- * default 2; a plan whose capture fails stays with 0):
+/* How the last glv_shard_run enqueued its steps and swaps (option "shard_graph" asks for a form;
+ * default -1: form 2 for shards of at least two workgroups per compute unit, else form 1; a plan
+ * whose capture fails stays with 0):
  *   0  every step and every swap enqueued by the host, one stream;
  *   1  the steps and swaps after the first swap replayed from one hipGraph;
  *   2  the same graph with two branches: the workgroups at the shard's two edges, which alone read
@@ -388,7 +389,10 @@ int glv_plan_last_loop_launches(const glv_plan* plan);
 /* Groups of consecutive utterances the last Griffin-Lim call was cut into (1: one piece).  A batch
  * with more runs than one iteration-spanning launch holds runs as several such launches, one per
  * group, one after the other; glv_plan_last_loop_launches then counts the launches of ONE group's
- * loop.  Option "group_frames": frames per group (0 = automatic, -1 = never cut). */
+ * loop.  A batch that would fit one launch only with very long runs is cut as well (a group's
+ * working set per iteration should fit the memory-side cache).  Option "group_frames": most frames
+ * per group (0 = automatic, -1 = never cut).  A row's bits are those of a call of its group alone;
+ * with a fixed run length (option "frames_per_run") they depend neither on the group nor on the cut. */
 int glv_plan_last_loop_groups(const glv_plan* plan);
 
 /*
