@@ -702,16 +702,16 @@ struct Engine {
         publish_preload(slot);
     }
     // the window-sum-square rows of blocks t_end .. t_end+R-2, requested after the last frame into
-    // the fetch buffers (their way from the cache passes under flush_tails)
-    // (one fetch buffer per block, those the frame loop uses first)
-    static constexpr bool kRingShape = A == 1 && R - 1 <= 6;
+    // the transform's work registers, idle until the next frame (their way from the cache passes
+    // under flush_tails)
+    // (hops of a quarter of the window and more: with seven boundary blocks the kernels would spill)
+    static constexpr bool kRingShape = A == 1 && (R - 1) * HB <= E && R <= 4;
     GLV_HD void fetch_ring_rows(const IterArgs& a) {
-        cf* dst[6] = {blk_n.main, blk_n.w, blkp_n.main, blk_n.tail, blkp_n.tail, blkp_n.w};
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) {
             const float* pw = iwss_row(a.iwss, a.iwss_head, a.iwss_tail, a.iwss_small, H, R, run.n_frames, run.t_end + q);
 #pragma unroll
-            for (int i = 0; i < HB; ++i) load_row(pw, i, dst[q]);
+            for (int i = 0; i < HB; ++i) load_row(pw, i, v + q * HB);
         }
     }
     // after flush_tails of a run with deposit_in (acc holds the complete sums of blocks t_end ..):
@@ -721,13 +721,12 @@ struct Engine {
     // load_block + combine_rows of a preload from memory.
     GLV_HD void ring_hand_over(const IterArgs& a, cf* slot, bool first) {
         static_assert(A == 1, "only the n_fft 1024 kernels share boundary blocks");
-        const cf* wrow[6] = {blk_n.main, blk_n.w, blkp_n.main, blk_n.tail, blkp_n.tail, blkp_n.w};
 #pragma unroll
         for (int q = 0; q < R - 1; ++q)
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
                 const int row = q * HB + i, at = row * (ROW / 2) + lane;
-                const cf cn = cf{acc[row].x * wrow[q][i].x, acc[row].y * wrow[q][i].y};
+                const cf cn = cf{acc[row].x * v[row].x, acc[row].y * v[row].y};
                 const cf pn = first ? slot[at] : ring_prev[at];
                 ring_prev[at] = cn;
                 slot[at] = cf{fmaf(-a.cmom, pn.x, cn.x), fmaf(-a.cmom, pn.y, cn.y)};
