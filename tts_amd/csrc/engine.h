@@ -346,6 +346,12 @@ struct Engine {
         lane = lane_;
         run = r;
         block_extra = a.raw_in ? 1 : 0;
+        share_next = nullptr;
+        deposit_out = nullptr;
+        deposit_in = nullptr;
+        ring_prev = nullptr;
+        heads_shared = false;
+        tails_shared = false;
     }
     GLV_HD void init(const IterArgs& a, const cf* tables, int lane_, const RunDesc& r) {
         lane = lane_;

@@ -172,6 +172,9 @@ __device__ __forceinline__ void enter_iteration(IterArgs& a, EngT& e, int& g_cur
 #ifndef GLV_COOP_PARTS
 #define GLV_COOP_PARTS 1
 #endif
+#ifndef GLV_EARLY_PRELOAD
+#define GLV_EARLY_PRELOAD 1
+#endif
 // 1: iteration-spanning kernels, n_fft 1024: a run that completes its boundary with the next run of
 // its workgroup also makes that boundary's hand-over for the next iteration, in LDS
 // (Engine::ring_hand_over): after the first iteration no run loads blocks that a wave of its own
@@ -261,6 +264,33 @@ gl_engine_kernel(IterArgs a) {
             r0.n_frames = __builtin_amdgcn_readfirstlane(r0.n_frames);
             e.init_run(a, threadIdx.x & 63, r0);
             e.template sum_blocks_for_workgroup<kWavesPerBlock>(a, t_first, wave0, tables + kSpan);
+        }
+    }
+    // The run kernels that take one launch per iteration (n_fft 1024) likewise ask for their run's
+    // first R-1 blocks before the tables are staged: which halves they read depends on the run
+    // table alone.
+    constexpr bool kEarly = GLV_EARLY_PRELOAD && !SC && A == 1 && GLV_SHARE_BOUNDARY &&
+                            (MODE == MODE_ITER_LIN || MODE == MODE_ITER_LIN_Z);
+    if constexpr (kEarly) {
+        const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wg0 = MODE == MODE_ITER_LIN ? a.wg_first + (int)blockIdx.x * (1 + a.wg_skip) : (int)blockIdx.x;
+        const int ri0 = wg0 * kWavesPerBlock + wave0;
+        if (ri0 < a.n_runs) {
+            RunDesc r0 = a.runs[ri0];
+            r0.utt = __builtin_amdgcn_readfirstlane(r0.utt);
+            r0.t_begin = __builtin_amdgcn_readfirstlane(r0.t_begin);
+            r0.t_end = __builtin_amdgcn_readfirstlane(r0.t_end);
+            r0.n_frames = __builtin_amdgcn_readfirstlane(r0.n_frames);
+            e.init_run(a, threadIdx.x & 63, r0);
+            if (kCanDeposit && a.deposit != 0) {
+                cf* area = tables + deposit_offset<A>();
+                if (wave0 > 0 && __builtin_amdgcn_readfirstlane(a.runs[ri0 - 1].utt) == r0.utt)
+                    e.deposit_out = area + (wave0 - 1) * (Eng::kShareFloats / 2);
+                if (wave0 + 1 < kWavesPerBlock && ri0 + 1 < a.n_runs &&
+                    __builtin_amdgcn_readfirstlane(a.runs[ri0 + 1].utt) == r0.utt)
+                    e.deposit_in = area + wave0 * (Eng::kShareFloats / 2);
+            }
+            e.template preload_lin<SC>(a);
         }
     }
     {
@@ -539,7 +569,7 @@ gl_engine_kernel(IterArgs a) {
             }
             GLV_SCHED_FENCE();
         } else if (live) {
-            e.template preload_lin<SC>(a);
+            if (!kEarly) e.template preload_lin<SC>(a);  // (else done before the tables were staged)
             e.publish_preload(mine);
         }
         // (with flags: once, so that every wave holds its tables in registers before the first deposit)
