@@ -1337,14 +1337,19 @@ struct Engine {
     }
 
     // what is left after the last frame belongs to blocks t_end .. t_end+R-2
-    GLV_HD void flush_tails(const IterArgs& a) {
+    // (store_complete = false: the complete blocks stay in `acc` for ring_hand_over and are not
+    // written - inside an iteration-spanning launch nobody reads them from memory before the last
+    // iteration has written them)
+    GLV_HD void flush_tails(const IterArgs& a, bool store_complete = true) {
         if constexpr (A == 1) {
             if (deposit_in != nullptr) {
                 // the next run's head sums + this run's tail sums = the complete blocks
 #pragma unroll
                 for (int row = 0; row < (R - 1) * HB; ++row) acc[row] = deposit_in[row * (ROW / 2) + lane] + acc[row];
+                if (store_complete) {
 #pragma unroll
-                for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out, run.t_end + q, acc, q * HB);
+                    for (int q = 0; q < R - 1; ++q) store_block(a, a.y_out, run.t_end + q, acc, q * HB);
+                }
                 return;
             }
         }

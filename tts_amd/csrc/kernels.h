@@ -172,6 +172,11 @@ __device__ __forceinline__ void enter_iteration(IterArgs& a, EngT& e, int& g_cur
 #ifndef GLV_COOP_PARTS
 #define GLV_COOP_PARTS 1
 #endif
+// 1 (with the ring): the blocks a run completes for the next run of its workgroup are written to
+// memory by the last iteration only
+#ifndef GLV_RING_SKIP_STORES
+#define GLV_RING_SKIP_STORES 1
+#endif
 #ifndef GLV_EARLY_PRELOAD
 #define GLV_EARLY_PRELOAD 1
 #endif
@@ -732,7 +737,7 @@ gl_engine_kernel(IterArgs a) {
     if constexpr (kRing) {
         if (e.ring_prev != nullptr) e.fetch_ring_rows(a);
     }
-    if (MODE != MODE_STFT && !kSingle) e.flush_tails(a);
+    if (MODE != MODE_STFT && !kSingle) e.flush_tails(a, !(kRing && GLV_RING_SKIP_STORES) || e.ring_prev == nullptr || k + 1 == n_outer);
     if constexpr (kRing) {
         if (e.ring_prev != nullptr) e.ring_hand_over(a, const_cast<cf*>(e.share_next), k == 0);
     }
